@@ -1,0 +1,154 @@
+/* C-ABI of the MI355X-native HDG / HDG-IMEX timestep engine (libhdg_mi355x.so).
+ *
+ * The reference (eikehmueller/IncompressibleEulerHDG) has no FFI boundary: its timestepper classes
+ * call Firedrake directly.  The seam cut here is the METHOD SURFACE of those classes; every entry
+ * point below names the reference code it replaces (paths relative to the reference's src/).
+ * Plain pointers and sizes only; every function returns 0 on success or a negative HDG_ERR_* code
+ * (message via hdg_last_error).  Nothing throws or aborts across this boundary.
+ *
+ * Ownership: the caller owns every host buffer (C-contiguous float64); the library owns all device
+ * memory and all stage vectors, which PERSIST across steps and solve() calls exactly like the
+ * reference's Function objects (timesteppers/hdg_imex.py:72-88,174-175,208).
+ * A handle is not thread-safe; all calls are synchronous on return.
+ *
+ * Field layout at the boundary (what Function.dat.data looks like in the reference):
+ *   velocity Q  (N_c * n_u, 2)  cell-major, node within cell, component fastest,  n_u = (k+2)(k+3)/2
+ *   pressure p  (N_c * n_p,)    n_p = (k+1)(k+2)/2
+ *   trace   lam (N_e * n_l,)    n_l = k+1
+ * Cell / edge / node numbering: see oracle/fem.py (documented there once; the product's C++ tables
+ * implement the same convention independently).
+ */
+#ifndef HDG_MI355X_H
+#define HDG_MI355X_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HDG_MAX_STAGES 5
+
+enum {
+  HDG_OK = 0,
+  HDG_ERR_ARG = -1,         /* bad argument / unsupported configuration */
+  HDG_ERR_HIP = -2,         /* HIP runtime error */
+  HDG_ERR_NOT_CONVERGED = -3, /* Krylov hit max iterations or broke down */
+  HDG_ERR_SINGULAR = -4,    /* singular local block while building tables */
+  HDG_ERR_UNSUPPORTED = -5
+};
+
+/* keys of hdg_pressure_solve (timesteppers/hdg_imex.py:258-272: "stage_i", "final_stage",
+ * "pressure_reconstruction").  Stage i is passed as the integer i >= 1. */
+#define HDG_KEY_FINAL_STAGE 0
+#define HDG_KEY_PRESSURE_RECONSTRUCTION -1
+
+/* `which` of hdg_shift_pressure / hdg_get_field */
+#define HDG_STATE_CURRENT 0   /* _current_state          (hdg_imex.py:175) */
+#define HDG_STATE_UPDATE -1   /* _update                 (hdg_imex.py:174) */
+#define HDG_STATE_RECON -2    /* _pressure_reconstruction (hdg_imex.py:208) */
+/* which = i >= 1 : _stage_state[i]; which = 100 + i: (_Q_tentative[i], -, -); 200 + i: (_Qstar[i], -, -) */
+
+typedef struct hdg_config {
+  int nx, ny;            /* UnitSquareMesh(nx, ny) triangles (driver.py:181); nx == ny required for GTMG */
+  int degree;            /* k = pressure degree (common.py:27), 1..4 */
+  double dt;
+  int flux_upwind;       /* 1 "upwind", 0 "centered" (hdg_imex.py:325) */
+  int use_projection;    /* hdg_imex.py:53 (0 -> HDG_ERR_UNSUPPORTED in this round) */
+  int n_richardson;      /* hdg_imex.py:60 */
+  double tau;            /* hdg_imex.py:58 */
+  double alpha_penalty;  /* hdg_imex.py:56 */
+  int nstages;           /* s; tableau arrays are row-major s x s / length s (hdg_imex.py:702-1038) */
+  double a_expl[HDG_MAX_STAGES * HDG_MAX_STAGES];
+  double a_impl[HDG_MAX_STAGES * HDG_MAX_STAGES];
+  double b_expl[HDG_MAX_STAGES];
+  double b_impl[HDG_MAX_STAGES + 1]; /* ARS3(4,4,3) carries 6 entries as written (hdg_imex.py:874) */
+  double c_expl[HDG_MAX_STAGES];
+  int equispaced_nodes;  /* 0: recursive GLL ("spectral") nodes, 1: equispaced lattice */
+  double tent_rtol;      /* 1e-10 (hdg_imex.py:226) */
+  int tent_maxit;
+  int gmres_restart;     /* PETSc default 30 */
+  int tent_precond;      /* 0 element block-Jacobi, 1 two-level (block-Jacobi + BDM-conforming correction) */
+  double trace_rtol;     /* 1e-12 (hdg_imex.py:137) */
+  int trace_maxit;
+  int trace_precond;     /* 0 edge block-Jacobi, 1 GTMG-like two-level (P1 coarse space + geometric MG) */
+  int device;            /* HIP device ordinal */
+} hdg_config;
+
+typedef struct hdg_handle hdg_handle;
+
+/* constructor of IncompressibleEulerHDGIMEX / IncompressibleEulerHDGImplicit
+ * (hdg_imex.py:29-255, hdg_implicit.py:17-50, common.py:23-73): spaces, 1/h_F, local operator tables,
+ * all persistent stage vectors (zero-initialised), solver workspaces. */
+int hdg_create(const hdg_config* cfg, hdg_handle** out);
+int hdg_destroy(hdg_handle* h);
+const char* hdg_last_error(const hdg_handle* h); /* h may be NULL for create errors */
+
+/* sizes: n_cells, n_edges, n_u, n_p, n_l */
+int hdg_get_sizes(const hdg_handle* h, long* n_cells, long* n_edges, int* n_u, int* n_p, int* n_l);
+
+/* interpolated initial condition -> _current_state (hdg_imex.py:520-533; hdg_implicit.py:82-84):
+ * nodal Q (N_c*n_u,2), nodal p (N_c*n_p); subtracts the pressure mean (hdg_imex.py:522). */
+int hdg_set_state(hdg_handle* h, const double* Q, const double* p);
+/* nodal copies of a state; any output pointer may be NULL */
+int hdg_get_field(hdg_handle* h, int which, double* Q, double* p, double* lam);
+/* overwrite a field (test hook; mirrors Function.assign) */
+int hdg_set_field(hdg_handle* h, int which, const double* Q, const double* p, const double* lam);
+
+/* forcing b_rhs[slot] <- interpolate f(t) (hdg_imex.py:554-557, slot = stage index; slot = nstages
+ * addresses _b_new, hdg_imex.py:629).  Nodal values (N_c*n_u, 2). */
+int hdg_set_forcing_nodal(hdg_handle* h, int slot, const double* f);
+/* separable forcing f(t) = g(t) * profile (Taylor-Green: model_problems.py:76-79): store the nodal
+ * profile once, then set b_rhs[slot] = scale * profile without moving data */
+int hdg_set_forcing_profile(hdg_handle* h, const double* profile);
+int hdg_set_forcing_scale(hdg_handle* h, int slot, double scale);
+
+/* _reconstruct_trace(_current_state) (hdg_imex.py:450-469) */
+int hdg_reconstruct_trace(hdg_handle* h);
+/* project_bdm (common.py:91-108): _Qstar[dst] <- BDM(_stage_state[src].Q)  (hdg_imex.py:565-567) */
+int hdg_project_bdm(hdg_handle* h, int src_stage, int dst);
+/* standalone project_bdm on caller data: nodal in -> nodal out (broken [P_{k+1}]^2 representation) */
+int hdg_project_bdm_nodal(hdg_handle* h, const double* Qin, double* Qout);
+/* _stage_state[0].assign(_current_state) (hdg_imex.py:558) */
+int hdg_begin_step(hdg_handle* h);
+/* tentative_velocity_solve("stage_i") (hdg_imex.py:274-281); returns Krylov iterations */
+int hdg_tentative_solve(hdg_handle* h, int stage, int* its);
+/* pressure_solve(key) (hdg_imex.py:257-272); returns condensed-Krylov iterations */
+int hdg_pressure_solve(hdg_handle* h, int key, int* its);
+/* _shift_pressure(state) (hdg_imex.py:471-478) */
+int hdg_shift_pressure(hdg_handle* h, int which);
+/* Richardson update of stage i (hdg_imex.py:580-599) */
+int hdg_stage_update(hdg_handle* h, int stage);
+/* copy p, lambda from _pressure_reconstruction into _current_state and shift (hdg_imex.py:633-637) */
+int hdg_finish_step(hdg_handle* h);
+/* the whole loop body hdg_imex.py:551-637, device resident; forcing slots must be set */
+int hdg_step(hdg_handle* h);
+/* nsteps fused steps with separable forcing: scales[n*(nstages+1) + slot] */
+int hdg_run_separable(hdg_handle* h, int nsteps, const double* scales);
+
+/* one step of IncompressibleEulerHDGImplicit.solve with the projection method
+ * (hdg_implicit.py:92-190); forcing slot 0 holds f(t_k) */
+int hdg_implicit_step(hdg_handle* h, int* its_tentative, int* its_pressure);
+
+/* iteration statistics accumulated since the last reset (hdg_imex.py:90-93,648-658):
+ * sums[4] / counts[4] for tentative, pressure, final pressure, pressure reconstruction */
+int hdg_get_iteration_stats(hdg_handle* h, double* sums, long* counts, int reset);
+
+/* physical coordinates of the DG nodes, boundary numbering: xq (N_c*n_u, 2), xp (N_c*n_p, 2); what
+ * `interpolate` evaluates expressions at (hdg_imex.py:520-521,555; model_problems.py:88-103) */
+int hdg_node_coordinates(hdg_handle* h, double* xq, double* xp);
+/* L2 norms of nodal fields (driver.py:376-377) and integral of a nodal pressure (model_problems.py:104) */
+int hdg_l2_norms(hdg_handle* h, const double* Q, const double* p, double* norm_Q, double* norm_p);
+int hdg_integrate_pressure(hdg_handle* h, const double* p, double* integral);
+
+/* kernel-level access for parity tests and micro-benchmarks (nodal in / nodal out) */
+int hdg_apply_advection(hdg_handle* h, const double* Qstar, const double* x, double gamma, double* y);
+int hdg_apply_trace_operator(hdg_handle* h, const double* lam, double* out);
+int hdg_apply_weak_divergence(hdg_handle* h, const double* Q, int broken, double* out_p);
+/* device-resident micro-benchmarks for bench.py: run `reps` launches of one kernel on the internal
+ * stream, return the average milliseconds per launch measured with HIP events on that stream.
+ * kernel: 0 advection apply, 1 trace apply, 2 BDM projection, 3 back-substitution */
+int hdg_time_kernel(hdg_handle* h, int kernel, int reps, double* ms_per_launch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,344 @@
+"""ctypes binding of libhdg_mi355x.so (C-ABI declared in include/hdg_mi355x.h).
+
+The product has no CPU fallback: if the HIP library is missing or a call fails, an exception is
+raised.  Nothing here imports ``oracle``.
+"""
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhdg_mi355x.so")
+SRC = os.path.join(_HERE, "csrc", "hdg_engine.hip")
+HEADER = os.path.normpath(os.path.join(_HERE, "..", "include", "hdg_mi355x.h"))
+
+HDG_MAX_STAGES = 5
+HDG_KEY_FINAL_STAGE = 0
+HDG_KEY_PRESSURE_RECONSTRUCTION = -1
+HDG_STATE_CURRENT = 0
+HDG_STATE_UPDATE = -1
+HDG_STATE_RECON = -2
+
+ERRORS = {-1: "HDG_ERR_ARG", -2: "HDG_ERR_HIP", -3: "HDG_ERR_NOT_CONVERGED", -4: "HDG_ERR_SINGULAR", -5: "HDG_ERR_UNSUPPORTED"}
+
+
+class HDGError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"{ERRORS.get(code, code)}: {msg}")
+        self.code = code
+
+
+class hdg_config(C.Structure):
+    _fields_ = [
+        ("nx", C.c_int),
+        ("ny", C.c_int),
+        ("degree", C.c_int),
+        ("dt", C.c_double),
+        ("flux_upwind", C.c_int),
+        ("use_projection", C.c_int),
+        ("n_richardson", C.c_int),
+        ("tau", C.c_double),
+        ("alpha_penalty", C.c_double),
+        ("nstages", C.c_int),
+        ("a_expl", C.c_double * (HDG_MAX_STAGES * HDG_MAX_STAGES)),
+        ("a_impl", C.c_double * (HDG_MAX_STAGES * HDG_MAX_STAGES)),
+        ("b_expl", C.c_double * HDG_MAX_STAGES),
+        ("b_impl", C.c_double * (HDG_MAX_STAGES + 1)),
+        ("c_expl", C.c_double * HDG_MAX_STAGES),
+        ("equispaced_nodes", C.c_int),
+        ("tent_rtol", C.c_double),
+        ("tent_maxit", C.c_int),
+        ("gmres_restart", C.c_int),
+        ("tent_precond", C.c_int),
+        ("trace_rtol", C.c_double),
+        ("trace_maxit", C.c_int),
+        ("trace_precond", C.c_int),
+        ("device", C.c_int),
+    ]
+
+
+def build_library(force=False, verbose=False):
+    """Compile the HIP engine for gfx950 into the package directory (in-tree, travels with gpurun)."""
+    srcs = [SRC, HEADER] + [os.path.join(_HERE, "csrc", f) for f in ("hdg_kernels.hpp", "hdg_tables.hpp")]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-o", LIB_PATH, SRC]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+_lib = None
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+_lp = C.POINTER(C.c_long)
+_h = C.c_void_p
+
+# every symbol include/hdg_mi355x.h declares, with its argument types
+SIGNATURES = {
+    "hdg_create": [C.POINTER(hdg_config), C.POINTER(_h)],
+    "hdg_destroy": [_h],
+    "hdg_get_sizes": [_h, _lp, _lp, _ip, _ip, _ip],
+    "hdg_set_state": [_h, _dp, _dp],
+    "hdg_get_field": [_h, C.c_int, _dp, _dp, _dp],
+    "hdg_set_field": [_h, C.c_int, _dp, _dp, _dp],
+    "hdg_set_forcing_nodal": [_h, C.c_int, _dp],
+    "hdg_set_forcing_profile": [_h, _dp],
+    "hdg_set_forcing_scale": [_h, C.c_int, C.c_double],
+    "hdg_reconstruct_trace": [_h],
+    "hdg_project_bdm": [_h, C.c_int, C.c_int],
+    "hdg_project_bdm_nodal": [_h, _dp, _dp],
+    "hdg_begin_step": [_h],
+    "hdg_tentative_solve": [_h, C.c_int, _ip],
+    "hdg_pressure_solve": [_h, C.c_int, _ip],
+    "hdg_shift_pressure": [_h, C.c_int],
+    "hdg_stage_update": [_h, C.c_int],
+    "hdg_finish_step": [_h],
+    "hdg_step": [_h],
+    "hdg_run_separable": [_h, C.c_int, _dp],
+    "hdg_implicit_step": [_h, _ip, _ip],
+    "hdg_get_iteration_stats": [_h, _dp, _lp, C.c_int],
+    "hdg_node_coordinates": [_h, _dp, _dp],
+    "hdg_l2_norms": [_h, _dp, _dp, _dp, _dp],
+    "hdg_integrate_pressure": [_h, _dp, _dp],
+    "hdg_apply_advection": [_h, _dp, _dp, C.c_double, _dp],
+    "hdg_apply_trace_operator": [_h, _dp, _dp],
+    "hdg_apply_weak_divergence": [_h, _dp, C.c_int, _dp],
+    "hdg_time_kernel": [_h, C.c_int, C.c_int, _dp],
+}
+
+
+def load_library():
+    """Load libhdg_mi355x.so; raise loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP engine has not been built "
+            "(run `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    lib.hdg_last_error.argtypes = [_h]
+    lib.hdg_last_error.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+def _arr(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and a.shape != tuple(shape):
+        raise ValueError(f"expected array of shape {shape}, got {a.shape}")
+    return a
+
+
+class Engine:
+    """Thin object wrapper around one hdg_handle."""
+
+    def __init__(self, **kw):
+        self.lib = load_library()
+        cfg = hdg_config()
+        s = int(kw["nstages"])
+        cfg.nx = int(kw["nx"])
+        cfg.ny = int(kw.get("ny", kw["nx"]))
+        cfg.degree = int(kw["degree"])
+        cfg.dt = float(kw["dt"])
+        cfg.flux_upwind = 1 if kw.get("flux", "upwind") == "upwind" else 0
+        cfg.use_projection = 1 if kw.get("use_projection_method", True) else 0
+        cfg.n_richardson = int(kw.get("n_richardson", 2))
+        cfg.tau = float(kw.get("tau", 1.0))
+        cfg.alpha_penalty = float(kw.get("alpha_penalty", 1.0))
+        cfg.nstages = s
+        a_e = np.zeros((HDG_MAX_STAGES, HDG_MAX_STAGES))
+        for name in ("a_expl", "a_impl"):
+            m = np.zeros(s * s)
+            if name in kw:
+                m[:] = np.asarray(kw[name], dtype=float).reshape(-1)[: s * s]
+            for i in range(s * s):
+                getattr(cfg, name)[i] = m[i]
+        for name, n in (("b_expl", s), ("b_impl", s), ("c_expl", s)):
+            if name in kw:
+                v = np.asarray(kw[name], dtype=float).reshape(-1)
+                for i in range(min(len(v), n if name != "b_impl" else HDG_MAX_STAGES + 1)):
+                    getattr(cfg, name)[i] = v[i]
+        del a_e
+        cfg.equispaced_nodes = 1 if kw.get("node_variant", "gll") == "equispaced" else 0
+        cfg.tent_rtol = float(kw.get("tent_rtol", 1e-10))
+        cfg.tent_maxit = int(kw.get("tent_maxit", 2000))
+        cfg.gmres_restart = int(kw.get("gmres_restart", 30))
+        cfg.tent_precond = int(kw.get("tent_precond", 1))
+        cfg.trace_rtol = float(kw.get("trace_rtol", 1e-12))
+        cfg.trace_maxit = int(kw.get("trace_maxit", 10000))
+        cfg.trace_precond = int(kw.get("trace_precond", 1))
+        cfg.device = int(kw.get("device", 0))
+        self.cfg = cfg
+        self.h = _h()
+        rc = self.lib.hdg_create(C.byref(cfg), C.byref(self.h))
+        if rc != 0:
+            raise HDGError(rc, self.lib.hdg_last_error(None).decode())
+        nc, ne = C.c_long(), C.c_long()
+        nu, np_, nl = C.c_int(), C.c_int(), C.c_int()
+        self._ck(self.lib.hdg_get_sizes(self.h, C.byref(nc), C.byref(ne), C.byref(nu), C.byref(np_), C.byref(nl)))
+        self.n_cells, self.n_edges = nc.value, ne.value
+        self.n_u, self.n_p, self.n_l = nu.value, np_.value, nl.value
+        self.nstages = s
+        self.shape_Q = (self.n_cells * self.n_u, 2)
+        self.shape_p = (self.n_cells * self.n_p,)
+        self.shape_l = (self.n_edges * self.n_l,)
+        # dimension of the mixed state (Q, p, lambda) advanced per step
+        self.n_total = self.n_cells * (2 * self.n_u + self.n_p) + self.n_edges * self.n_l
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise HDGError(rc, self.lib.hdg_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.hdg_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # --- state
+    def set_state(self, Q, p):
+        Q, p = _arr(Q, self.shape_Q), _arr(p, self.shape_p)
+        self._ck(self.lib.hdg_set_state(self.h, _ptr(Q), _ptr(p)))
+
+    def get_field(self, which, Q=True, p=True, lam=True):
+        oQ = np.empty(self.shape_Q) if Q else None
+        op = np.empty(self.shape_p) if p else None
+        ol = np.empty(self.shape_l) if lam else None
+        self._ck(self.lib.hdg_get_field(self.h, which, _ptr(oQ), _ptr(op), _ptr(ol)))
+        return oQ, op, ol
+
+    def set_field(self, which, Q=None, p=None, lam=None):
+        Q = None if Q is None else _arr(Q, self.shape_Q)
+        p = None if p is None else _arr(p, self.shape_p)
+        lam = None if lam is None else _arr(lam, self.shape_l)
+        self._ck(self.lib.hdg_set_field(self.h, which, _ptr(Q), _ptr(p), _ptr(lam)))
+
+    def set_forcing_nodal(self, slot, f):
+        f = _arr(f, self.shape_Q)
+        self._ck(self.lib.hdg_set_forcing_nodal(self.h, slot, _ptr(f)))
+
+    def set_forcing_profile(self, profile):
+        f = _arr(profile, self.shape_Q)
+        self._ck(self.lib.hdg_set_forcing_profile(self.h, _ptr(f)))
+
+    def set_forcing_scale(self, slot, scale):
+        self._ck(self.lib.hdg_set_forcing_scale(self.h, slot, float(scale)))
+
+    # --- pieces of the solve loop
+    def reconstruct_trace(self):
+        self._ck(self.lib.hdg_reconstruct_trace(self.h))
+
+    def project_bdm(self, src_stage, dst):
+        self._ck(self.lib.hdg_project_bdm(self.h, src_stage, dst))
+
+    def project_bdm_nodal(self, Q):
+        Q = _arr(Q, self.shape_Q)
+        out = np.empty(self.shape_Q)
+        self._ck(self.lib.hdg_project_bdm_nodal(self.h, _ptr(Q), _ptr(out)))
+        return out
+
+    def begin_step(self):
+        self._ck(self.lib.hdg_begin_step(self.h))
+
+    def tentative_solve(self, stage):
+        its = C.c_int()
+        self._ck(self.lib.hdg_tentative_solve(self.h, stage, C.byref(its)))
+        return its.value
+
+    def pressure_solve(self, key):
+        its = C.c_int()
+        self._ck(self.lib.hdg_pressure_solve(self.h, key, C.byref(its)))
+        return its.value
+
+    def shift_pressure(self, which):
+        self._ck(self.lib.hdg_shift_pressure(self.h, which))
+
+    def stage_update(self, stage):
+        self._ck(self.lib.hdg_stage_update(self.h, stage))
+
+    def finish_step(self):
+        self._ck(self.lib.hdg_finish_step(self.h))
+
+    def step(self):
+        self._ck(self.lib.hdg_step(self.h))
+
+    def run_separable(self, scales):
+        scales = _arr(scales)
+        assert scales.ndim == 2 and scales.shape[1] == self.nstages + 1
+        self._ck(self.lib.hdg_run_separable(self.h, scales.shape[0], _ptr(scales)))
+
+    def implicit_step(self):
+        a, b = C.c_int(), C.c_int()
+        self._ck(self.lib.hdg_implicit_step(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def iteration_stats(self, reset=False):
+        sums = np.zeros(4)
+        cnt = np.zeros(4, dtype=np.int64)
+        self._ck(self.lib.hdg_get_iteration_stats(self.h, _ptr(sums), cnt.ctypes.data_as(_lp), 1 if reset else 0))
+        return sums, cnt
+
+    # --- helpers
+    def node_coordinates(self):
+        xq = np.empty(self.shape_Q)
+        xp = np.empty((self.n_cells * self.n_p, 2))
+        self._ck(self.lib.hdg_node_coordinates(self.h, _ptr(xq), _ptr(xp)))
+        return xq, xp
+
+    def l2_norms(self, Q=None, p=None):
+        nq, npv = C.c_double(0.0), C.c_double(0.0)
+        Q = None if Q is None else _arr(Q, self.shape_Q)
+        p = None if p is None else _arr(p, self.shape_p)
+        self._ck(self.lib.hdg_l2_norms(self.h, _ptr(Q), _ptr(p), C.byref(nq), C.byref(npv)))
+        return nq.value, npv.value
+
+    def integrate_pressure(self, p):
+        p = _arr(p, self.shape_p)
+        out = C.c_double()
+        self._ck(self.lib.hdg_integrate_pressure(self.h, _ptr(p), C.byref(out)))
+        return out.value
+
+    def apply_advection(self, Qstar, x, gamma):
+        Qstar, x = _arr(Qstar, self.shape_Q), _arr(x, self.shape_Q)
+        y = np.empty(self.shape_Q)
+        self._ck(self.lib.hdg_apply_advection(self.h, _ptr(Qstar), _ptr(x), float(gamma), _ptr(y)))
+        return y
+
+    def apply_trace_operator(self, lam):
+        lam = _arr(lam, self.shape_l)
+        out = np.empty(self.shape_l)
+        self._ck(self.lib.hdg_apply_trace_operator(self.h, _ptr(lam), _ptr(out)))
+        return out
+
+    def apply_weak_divergence(self, Q, broken=False):
+        Q = _arr(Q, self.shape_Q)
+        out = np.empty(self.shape_p)
+        self._ck(self.lib.hdg_apply_weak_divergence(self.h, _ptr(Q), 1 if broken else 0, _ptr(out)))
+        return out
+
+    def time_kernel(self, kernel, reps):
+        ms = C.c_double()
+        self._ck(self.lib.hdg_time_kernel(self.h, kernel, reps, C.byref(ms)))
+        return ms.value

@@ -1,0 +1,1001 @@
+// Hand-written HIP kernels (gfx950 / CDNA4) for the HDG / HDG-IMEX timestep hot path.
+//
+// Data layout in HBM (all float64, modal coefficients in PHYSICALLY orthonormal bases):
+//   cell vectors   v[(n * Nc) + c],  c = (s*ny + j)*nx + i   (dof-major, cell fastest;
+//                  consecutive lanes <-> consecutive i  => every global access is coalesced)
+//   velocity       n = d*NU + m  (component d, Dubiner mode m),  pressure n = m
+//   trace vectors  l[((t*NL + m) * G) + j*P + i],  t = 0 (H), 1 (V), 2 (D),  corner-indexed on a
+//                  padded (ny+1) x P grid; entries that are not edges stay exactly zero.
+// One thread owns one cell (or one grid corner = up to three edges); the element shape s is
+// uniform per block (blockIdx.z), so every operator-table read is a wave-uniform scalar load
+// (s_load_*) served by the scalar cache - local matrices never occupy vector registers or LDS
+// bandwidth, and the FP64 FMA pipe sees one VGPR + one SGPR operand pair per instruction.
+// Facet coupling is done by neighbour GATHER (owner computes), never by atomics, so results are
+// bitwise reproducible.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace hdg {
+
+struct Geo {
+  int nx, ny, P;
+  long G;   // (ny+1)*P : one trace plane
+  long Nc;  // 2*nx*ny
+  double h;
+};
+
+template <int K>
+struct Dim {
+  static constexpr int NU = (K + 2) * (K + 3) / 2;
+  static constexpr int NP = (K + 1) * (K + 2) / 2;
+  static constexpr int NL = K + 1;
+  static constexpr int NE = K + 2;
+  static constexpr int NX = 2 * NU + NP;
+  static constexpr int NT = 3 * NL;
+};
+
+struct DevTables {
+  const double *N[2][3], *Nt[2][3], *Lift[2][3], *LiftT[2][3], *Pt[2][3];
+  const double *B[2], *D0[2], *Ainv[2], *W[2], *Y[2], *SK[2];
+  const double *cw, *cPhi[2], *cGx[2], *cGy[2];
+  const double *ew[3], *ePhi[2][3], *eGx[2][3], *eGy[2][3];
+  const double* trDinv[3][3];
+  const double *Vu, *Vuinv, *Vp, *Vpinv, *Vl, *Vlinv;
+  double elen[3], enx[3], eny[3], sig[2][3];
+  double h, tau, alpha;
+  int nqc, nqe;
+};
+
+#define HDG_CELL_PROLOGUE                                   \
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;      \
+  const int j = blockIdx.y;                                 \
+  const int s = blockIdx.z;                                 \
+  if (i >= g.nx) return;                                    \
+  const long c = ((long)s * g.ny + j) * g.nx + i;
+
+__device__ __forceinline__ bool nbr(int s, int e, int i, int j, const Geo& g, long& cn) {
+  int in, jn;
+  bool ok;
+  if (s == 0) {
+    if (e == 0) { in = i; jn = j - 1; ok = j > 0; }
+    else if (e == 1) { in = i; jn = j; ok = true; }
+    else { in = i - 1; jn = j; ok = i > 0; }
+  } else {
+    if (e == 0) { in = i; jn = j + 1; ok = j < g.ny - 1; }
+    else if (e == 1) { in = i; jn = j; ok = true; }
+    else { in = i + 1; jn = j; ok = i < g.nx - 1; }
+  }
+  cn = ((long)(1 - s) * g.ny + jn) * g.nx + in;
+  return ok;
+}
+
+// offset (within a trace plane) and type of local edge e of cell (s,i,j)
+__device__ __forceinline__ long edge_off(int s, int e, int i, int j, const Geo& g, int& t) {
+  if (e == 0) { t = 0; return (long)(j + s) * g.P + i; }
+  if (e == 1) { t = 2; return (long)j * g.P + i; }
+  t = 1;
+  return (long)j * g.P + i + s;
+}
+
+template <int N>
+__device__ __forceinline__ void load_cell(const double* __restrict__ v, long Nc, long c, double (&x)[N]) {
+#pragma unroll
+  for (int n = 0; n < N; n++) x[n] = v[(long)n * Nc + c];
+}
+template <int N>
+__device__ __forceinline__ void store_cell(double* __restrict__ v, long Nc, long c, const double (&x)[N]) {
+#pragma unroll
+  for (int n = 0; n < N; n++) v[(long)n * Nc + c] = x[n];
+}
+
+// y[r] += sc * sum_c A[r*NC + c] x[c]   (A wave-uniform -> scalar loads)
+template <int NR, int NC>
+__device__ __forceinline__ void mv_acc(const double* __restrict__ A, const double (&x)[NC], double (&y)[NR], double sc) {
+#pragma unroll
+  for (int r = 0; r < NR; r++) {
+    double acc = 0.0;
+#pragma unroll
+    for (int cc = 0; cc < NC; cc++) acc = fma(A[r * NC + cc], x[cc], acc);
+    y[r] = fma(sc, acc, y[r]);
+  }
+}
+// same with a row stride LD >= NC (use the first NR rows / a column window of a larger matrix)
+template <int NR, int NC>
+__device__ __forceinline__ void mv_acc_ld(const double* __restrict__ A, int LD, const double* x, double* y, double sc) {
+#pragma unroll
+  for (int r = 0; r < NR; r++) {
+    double acc = 0.0;
+#pragma unroll
+    for (int cc = 0; cc < NC; cc++) acc = fma(A[r * LD + cc], x[cc], acc);
+    y[r] = fma(sc, acc, y[r]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K1  edge_lift:  out_K = in_K + sum_e Out_e * w * (In_e^{K'} in_K' - In_e^{K} in_K)
+//   w = 1/2 on interior edges; on boundary edges w = 1 and the neighbour term is absent.
+//   With (In, Out) = (N, Lift) this is the BDM projection Q -> Q* (common.py:91-108);
+//   with (In, Out) = (Lift^T, N^T) it is its transpose (used by the two-level preconditioner).
+// ------------------------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(128) void k_edge_lift(Geo g, const double* __restrict__ in, double* __restrict__ out,
+                                                    const double* const* __restrict__ tabIn,
+                                                    const double* const* __restrict__ tabOut) {
+  constexpr int NU = Dim<K>::NU, NE = Dim<K>::NE, N2 = 2 * NU;
+  HDG_CELL_PROLOGUE
+  double x[N2], y[N2];
+  load_cell<N2>(in, g.Nc, c, x);
+#pragma unroll
+  for (int n = 0; n < N2; n++) y[n] = x[n];
+#pragma unroll
+  for (int e = 0; e < 3; e++) {
+    double d[NE];
+#pragma unroll
+    for (int a = 0; a < NE; a++) d[a] = 0.0;
+    mv_acc<NE, N2>(tabIn[s * 3 + e], x, d, -1.0);
+    long cn;
+    if (nbr(s, e, i, j, g, cn)) {
+      double xn[N2];
+      load_cell<N2>(in, g.Nc, cn, xn);
+      mv_acc<NE, N2>(tabIn[(1 - s) * 3 + e], xn, d, 1.0);
+#pragma unroll
+      for (int a = 0; a < NE; a++) d[a] *= 0.5;
+    }
+    mv_acc<N2, NE>(tabOut[s * 3 + e], d, y, 1.0);
+  }
+  store_cell<N2>(out, g.Nc, c, y);
+}
+
+// ------------------------------------------------------------------------------------------
+// K3  advection apply:  y = x - gamma * F(Q*) x     with F = f_impl (hdg_imex.py:313-331):
+//   F_K(x)[w] = sum_{e int} int_e [ (1/2)(Q*.n_K) - up |Q*.n_K| ] (x_K - x_K').w
+//             - int_K w.((Q*.grad) x)  -  sum_e alpha/h_F int_e ((x_K - x_K').n)(w.n)
+//   (x_K' := 0 on boundary edges; Q*.n = 0 there).  Quadrature: cell rule exact to 3k+2, edge rule
+//   ceil((3k+4)/2) Gauss points (the |Q*.n| integrand is not polynomial: SURVEY.md App. D.3).
+// ------------------------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(128) void k_adv_apply(Geo g, DevTables T, const double* __restrict__ xin,
+                                                    const double* __restrict__ qstar, double* __restrict__ out,
+                                                    double gamma, double upwind) {
+  constexpr int NU = Dim<K>::NU, N2 = 2 * NU;
+  HDG_CELL_PROLOGUE
+  double x[N2], qs[N2], F[N2];
+  load_cell<N2>(xin, g.Nc, c, x);
+  load_cell<N2>(qstar, g.Nc, c, qs);
+#pragma unroll
+  for (int n = 0; n < N2; n++) F[n] = 0.0;
+  // ---- cell term
+  {
+    const double* __restrict__ Phi = T.cPhi[s];
+    const double* __restrict__ Gx = T.cGx[s];
+    const double* __restrict__ Gy = T.cGy[s];
+    const int nq = T.nqc;
+#pragma unroll 1
+    for (int q = 0; q < nq; q++) {
+      double qx = 0, qy = 0, dxx = 0, dxy = 0, dyx = 0, dyy = 0;  // dab = d_b x_a
+#pragma unroll
+      for (int m = 0; m < NU; m++) {
+        const double ph = Phi[q * NU + m], gx = Gx[q * NU + m], gy = Gy[q * NU + m];
+        qx = fma(ph, qs[m], qx);
+        qy = fma(ph, qs[NU + m], qy);
+        dxx = fma(gx, x[m], dxx);
+        dxy = fma(gy, x[m], dxy);
+        dyx = fma(gx, x[NU + m], dyx);
+        dyy = fma(gy, x[NU + m], dyy);
+      }
+      const double w = T.cw[q];
+      const double ax = -w * (qx * dxx + qy * dxy);
+      const double ay = -w * (qx * dyx + qy * dyy);
+#pragma unroll
+      for (int m = 0; m < NU; m++) {
+        const double ph = Phi[q * NU + m];
+        F[m] = fma(ph, ax, F[m]);
+        F[NU + m] = fma(ph, ay, F[NU + m]);
+      }
+    }
+  }
+  // ---- facet terms
+#pragma unroll
+  for (int e = 0; e < 3; e++) {
+    long cn;
+    const bool has = nbr(s, e, i, j, g, cn);
+    double xn[N2];
+    if (has) load_cell<N2>(xin, g.Nc, cn, xn);
+    else {
+#pragma unroll
+      for (int n = 0; n < N2; n++) xn[n] = 0.0;
+    }
+    const double* __restrict__ Po = T.ePhi[s][e];
+    const double* __restrict__ Pn = T.ePhi[1 - s][e];
+    const double nx_ = T.enx[e], ny_ = T.eny[e], sg = T.sig[s][e];
+    const double pen = T.alpha / T.elen[e];
+    const int nq = T.nqe;
+#pragma unroll 1
+    for (int q = 0; q < nq; q++) {
+      double ox = 0, oy = 0, bx = 0, by = 0, qn = 0;
+#pragma unroll
+      for (int m = 0; m < NU; m++) {
+        const double po = Po[q * NU + m], pn = Pn[q * NU + m];
+        ox = fma(po, x[m], ox);
+        oy = fma(po, x[NU + m], oy);
+        bx = fma(pn, xn[m], bx);
+        by = fma(pn, xn[NU + m], by);
+        qn = fma(po, fma(nx_, qs[m], ny_ * qs[NU + m]), qn);
+      }
+      const double w = T.ew[e][q];
+      const double cf = has ? w * (0.5 * sg * qn - upwind * fabs(qn)) : 0.0;
+      const double jx = ox - bx, jy = oy - by;
+      const double jn = (jx * nx_ + jy * ny_) * pen * w;
+      const double vx = cf * jx - jn * nx_;
+      const double vy = cf * jy - jn * ny_;
+#pragma unroll
+      for (int m = 0; m < NU; m++) {
+        const double po = Po[q * NU + m];
+        F[m] = fma(po, vx, F[m]);
+        F[NU + m] = fma(po, vy, F[NU + m]);
+      }
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < N2; n++) out[(long)n * g.Nc + c] = fma(-gamma, F[n], x[n]);
+}
+
+// ------------------------------------------------------------------------------------------
+// K4  element block-Jacobi:  out = cz * zin + Dinv_s * r      (Dinv: 2NU x 2NU per shape)
+// ------------------------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(128) void k_blockdiag(Geo g, const double* __restrict__ Dinv0,
+                                                    const double* __restrict__ Dinv1, const double* __restrict__ r,
+                                                    const double* __restrict__ zin, double cz, double* __restrict__ out) {
+  constexpr int N2 = 2 * Dim<K>::NU;
+  HDG_CELL_PROLOGUE
+  double x[N2], y[N2];
+  load_cell<N2>(r, g.Nc, c, x);
+  if (zin) {
+    load_cell<N2>(zin, g.Nc, c, y);
+#pragma unroll
+    for (int n = 0; n < N2; n++) y[n] *= cz;
+  } else {
+#pragma unroll
+    for (int n = 0; n < N2; n++) y[n] = 0.0;
+  }
+  mv_acc<N2, N2>(s == 0 ? Dinv0 : Dinv1, x, y, 1.0);
+  store_cell<N2>(out, g.Nc, c, y);
+}
+
+// ------------------------------------------------------------------------------------------
+// pressure gradient:  out = ca*a + cb*b + gamma * ( B^T p - sum_e C_e^T lambda_e )
+//   g(w,p,lambda) = (p, div w)_K - <lambda, w.n_K>_{dK}   (hdg_imex.py:333-340)
+// ------------------------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(128) void k_pgrad(Geo g, DevTables T, const double* __restrict__ a, double ca,
+                                                const double* __restrict__ b, double cb, const double* __restrict__ p,
+                                                const double* __restrict__ lam, double gamma, double* __restrict__ out) {
+  constexpr int NU = Dim<K>::NU, NP = Dim<K>::NP, NL = Dim<K>::NL, N2 = 2 * NU;
+  HDG_CELL_PROLOGUE
+  double y[N2], pp[NP], acc[N2];
+#pragma unroll
+  for (int n = 0; n < N2; n++) {
+    y[n] = (a ? ca * a[(long)n * g.Nc + c] : 0.0) + (b ? cb * b[(long)n * g.Nc + c] : 0.0);
+    acc[n] = 0.0;
+  }
+  load_cell<NP>(p, g.Nc, c, pp);
+  const double* __restrict__ Bm = T.B[s];
+#pragma unroll
+  for (int n = 0; n < N2; n++) {
+    double v = 0.0;
+#pragma unroll
+    for (int r = 0; r < NP; r++) v = fma(Bm[r * N2 + n], pp[r], v);
+    acc[n] = v;
+  }
+#pragma unroll
+  for (int e = 0; e < 3; e++) {
+    int t;
+    const long off = edge_off(s, e, i, j, g, t);
+    double l[NL];
+#pragma unroll
+    for (int m = 0; m < NL; m++) l[m] = lam[((long)t * NL + m) * g.G + off];
+    const double* __restrict__ Nm = T.N[s][e];
+    const double sg = T.sig[s][e];
+#pragma unroll
+    for (int n = 0; n < N2; n++) {
+      double v = 0.0;
+#pragma unroll
+      for (int m = 0; m < NL; m++) v = fma(Nm[m * N2 + n], l[m], v);
+      acc[n] = fma(-sg, v, acc[n]);
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < N2; n++) out[(long)n * g.Nc + c] = fma(gamma, acc[n], y[n]);
+}
+
+// ------------------------------------------------------------------------------------------
+// weak divergence (hdg_imex.py:353-365):  out = sc * [ -(grad psi, Q)_K + <psi, {{Q}}.n>_{dK, int} ]
+//   BROKEN = true gives sc * (psi, div Q)_K instead (hdg_implicit.py:145)
+// ------------------------------------------------------------------------------------------
+template <int K, bool BROKEN>
+__global__ __launch_bounds__(128) void k_weak_div(Geo g, DevTables T, const double* __restrict__ q, double sc,
+                                                   double* __restrict__ out) {
+  constexpr int NU = Dim<K>::NU, NP = Dim<K>::NP, NL = Dim<K>::NL, N2 = 2 * NU;
+  HDG_CELL_PROLOGUE
+  double x[N2], y[NP];
+  load_cell<N2>(q, g.Nc, c, x);
+#pragma unroll
+  for (int r = 0; r < NP; r++) y[r] = 0.0;
+  if (BROKEN) {
+    mv_acc<NP, N2>(T.B[s], x, y, 1.0);
+  } else {
+    mv_acc<NP, N2>(T.D0[s], x, y, 1.0);
+#pragma unroll
+    for (int e = 0; e < 3; e++) {
+      long cn;
+      if (nbr(s, e, i, j, g, cn)) {
+        double xn[N2], tr[NL];
+        load_cell<N2>(q, g.Nc, cn, xn);
+#pragma unroll
+        for (int m = 0; m < NL; m++) tr[m] = 0.0;
+        mv_acc_ld<NL, N2>(T.N[s][e], N2, x, tr, 0.5);
+        mv_acc_ld<NL, N2>(T.N[1 - s][e], N2, xn, tr, 0.5);
+        const double* __restrict__ Pm = T.Pt[s][e];
+        const double sg = T.sig[s][e];
+#pragma unroll
+        for (int r = 0; r < NP; r++) {
+          double v = 0.0;
+#pragma unroll
+          for (int m = 0; m < NL; m++) v = fma(Pm[m * NP + r], tr[m], v);
+          y[r] = fma(sg, v, y[r]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < NP; r++) out[(long)r * g.Nc + c] = sc * y[r];
+}
+
+// ------------------------------------------------------------------------------------------
+// corner-thread helpers for the trace space
+// ------------------------------------------------------------------------------------------
+#define HDG_CORNER_PROLOGUE                               \
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;    \
+  const int j = blockIdx.y;                               \
+  if (i > g.nx) return;                                   \
+  const long o = (long)j * g.P + i;                       \
+  const bool in_x = i < g.nx, in_y = j < g.ny;
+
+template <int NL>
+__device__ __forceinline__ void load_tr(const double* __restrict__ l, const Geo& g, int t, long off, double* v) {
+#pragma unroll
+  for (int m = 0; m < NL; m++) v[m] = l[((long)t * NL + m) * g.G + off];
+}
+
+// K6  trace apply (condensed Schur operator of firedrake.SCPC, hdg_imex.py:128-135), SPD form:
+//   out = cb*base + ct * (-S) lam
+template <int K>
+__global__ __launch_bounds__(128) void k_trace_apply(Geo g, DevTables T, const double* __restrict__ lam,
+                                                      const double* __restrict__ base, double cb, double ct,
+                                                      double* __restrict__ out) {
+  constexpr int NL = Dim<K>::NL, NT = 3 * NL;
+  HDG_CORNER_PROLOGUE
+  double yH[NL], yV[NL], yD[NL];
+#pragma unroll
+  for (int m = 0; m < NL; m++) yH[m] = yV[m] = yD[m] = 0.0;
+  const double* __restrict__ SL = T.SK[0];
+  const double* __restrict__ SU = T.SK[1];
+  double own[NT];  // (H0, D0, V0) in local-edge order e0,e1,e2 of L(i,j)
+  if (in_x) load_tr<NL>(lam, g, 0, o, own); else { for (int m = 0; m < NL; m++) own[m] = 0.0; }
+  if (in_x && in_y) load_tr<NL>(lam, g, 2, o, own + NL); else { for (int m = 0; m < NL; m++) own[NL + m] = 0.0; }
+  if (in_y) load_tr<NL>(lam, g, 1, o, own + 2 * NL); else { for (int m = 0; m < NL; m++) own[2 * NL + m] = 0.0; }
+  if (in_x && in_y) {  // L(i,j): all three rows
+    mv_acc_ld<NL, NT>(SL + 0 * NL * NT, NT, own, yH, -1.0);
+    mv_acc_ld<NL, NT>(SL + 1 * NL * NT, NT, own, yD, -1.0);
+    mv_acc_ld<NL, NT>(SL + 2 * NL * NT, NT, own, yV, -1.0);
+    // U(i,j): edges (H(i,j+1), D(i,j), V(i+1,j)), row block e1 -> D
+    double u[NT];
+    load_tr<NL>(lam, g, 0, o + g.P, u);
+#pragma unroll
+    for (int m = 0; m < NL; m++) u[NL + m] = own[NL + m];
+    load_tr<NL>(lam, g, 1, o + 1, u + 2 * NL);
+    mv_acc_ld<NL, NT>(SU + 1 * NL * NT, NT, u, yD, -1.0);
+  }
+  if (in_x && j > 0) {  // U(i,j-1): edges (H(i,j), D(i,j-1), V(i+1,j-1)), row block e0 -> H
+    double u[NT];
+#pragma unroll
+    for (int m = 0; m < NL; m++) u[m] = own[m];
+    load_tr<NL>(lam, g, 2, o - g.P, u + NL);
+    load_tr<NL>(lam, g, 1, o - g.P + 1, u + 2 * NL);
+    mv_acc_ld<NL, NT>(SU + 0 * NL * NT, NT, u, yH, -1.0);
+  }
+  if (in_y && i > 0) {  // U(i-1,j): edges (H(i-1,j+1), D(i-1,j), V(i,j)), row block e2 -> V
+    double u[NT];
+    load_tr<NL>(lam, g, 0, o + g.P - 1, u);
+    load_tr<NL>(lam, g, 2, o - 1, u + NL);
+#pragma unroll
+    for (int m = 0; m < NL; m++) u[2 * NL + m] = own[2 * NL + m];
+    mv_acc_ld<NL, NT>(SU + 2 * NL * NT, NT, u, yV, -1.0);
+  }
+#pragma unroll
+  for (int m = 0; m < NL; m++) {
+    const long iH = ((long)0 * NL + m) * g.G + o, iV = ((long)1 * NL + m) * g.G + o, iD = ((long)2 * NL + m) * g.G + o;
+    double bH = 0, bV = 0, bD = 0;
+    if (base) { bH = cb * base[iH]; bV = cb * base[iV]; bD = cb * base[iD]; }
+    out[iH] = in_x ? fma(ct, yH[m], bH) : 0.0;
+    out[iV] = in_y ? fma(ct, yV[m], bV) : 0.0;
+    out[iD] = (in_x && in_y) ? fma(ct, yD[m], bD) : 0.0;
+  }
+}
+
+// edge-block Jacobi / Chebyshev update on the trace space:
+//   d = c1*d + c2 * Dinv r ;  x += d        (ASMStarPC with construct_dim=1: one block per facet)
+template <int K>
+__global__ __launch_bounds__(128) void k_trace_cheb(Geo g, DevTables T, const double* __restrict__ r, double* __restrict__ d,
+                                                     double* __restrict__ x, double c1, double c2) {
+  constexpr int NL = Dim<K>::NL;
+  HDG_CORNER_PROLOGUE
+#pragma unroll
+  for (int t = 0; t < 3; t++) {
+    bool valid;
+    int var;
+    if (t == 0) { valid = in_x; var = (j == 0) ? 1 : (j == g.ny ? 2 : 0); }
+    else if (t == 1) { valid = in_y; var = (i == 0) ? 1 : (i == g.nx ? 2 : 0); }
+    else { valid = in_x && in_y; var = 0; }
+    if (!valid) continue;
+    double rr[NL], z[NL];
+    load_tr<NL>(r, g, t, o, rr);
+#pragma unroll
+    for (int m = 0; m < NL; m++) z[m] = 0.0;
+    const double* __restrict__ Dm = T.trDinv[t][var];
+    mv_acc_ld<NL, NL>(Dm, NL, rr, z, 1.0);
+#pragma unroll
+    for (int m = 0; m < NL; m++) {
+      const long idx = ((long)t * NL + m) * g.G + o;
+      const double dn = fma(c1, (c1 != 0.0 ? d[idx] : 0.0), c2 * z[m]);
+      d[idx] = dn;
+      if (x) x[idx] += dn;
+    }
+  }
+}
+
+// K5  condensed right-hand side (SCPC forward elimination), SPD sign convention:
+//   out_e = sum_{K contains e} (Y_K r_{x,K})_e  -  r_lambda,e       with r_x = (rw, rp)
+template <int K, bool HASW, bool HASP>
+__device__ __forceinline__ void y_rows(const double* __restrict__ Y, int erow, const double* __restrict__ rw,
+                                       const double* __restrict__ rp, long Nc, long c, double* acc) {
+  constexpr int NU = Dim<K>::NU, NP = Dim<K>::NP, NL = Dim<K>::NL, NX = Dim<K>::NX, N2 = 2 * NU;
+  if (HASW) {
+    double x[N2];
+    load_cell<N2>(rw, Nc, c, x);
+    mv_acc_ld<NL, N2>(Y + (long)erow * NL * NX, NX, x, acc, 1.0);
+  }
+  if (HASP) {
+    double x[NP];
+    load_cell<NP>(rp, Nc, c, x);
+    mv_acc_ld<NL, NP>(Y + (long)erow * NL * NX + N2, NX, x, acc, 1.0);
+  }
+}
+
+template <int K, bool HASW, bool HASP>
+__global__ __launch_bounds__(128) void k_condense(Geo g, DevTables T, const double* __restrict__ rw,
+                                                   const double* __restrict__ rp, const double* __restrict__ rl,
+                                                   double* __restrict__ out) {
+  constexpr int NL = Dim<K>::NL;
+  HDG_CORNER_PROLOGUE
+  double yH[NL], yV[NL], yD[NL];
+#pragma unroll
+  for (int m = 0; m < NL; m++) yH[m] = yV[m] = yD[m] = 0.0;
+  const long nxy = (long)g.nx * g.ny;
+  if (in_x && in_y) {
+    const long cL = (long)j * g.nx + i, cU = nxy + cL;
+    y_rows<K, HASW, HASP>(T.Y[0], 0, rw, rp, g.Nc, cL, yH);
+    y_rows<K, HASW, HASP>(T.Y[0], 1, rw, rp, g.Nc, cL, yD);
+    y_rows<K, HASW, HASP>(T.Y[0], 2, rw, rp, g.Nc, cL, yV);
+    y_rows<K, HASW, HASP>(T.Y[1], 1, rw, rp, g.Nc, cU, yD);
+  }
+  if (in_x && j > 0) y_rows<K, HASW, HASP>(T.Y[1], 0, rw, rp, g.Nc, nxy + (long)(j - 1) * g.nx + i, yH);
+  if (in_y && i > 0) y_rows<K, HASW, HASP>(T.Y[1], 2, rw, rp, g.Nc, nxy + (long)j * g.nx + i - 1, yV);
+#pragma unroll
+  for (int m = 0; m < NL; m++) {
+    const long iH = ((long)0 * NL + m) * g.G + o, iV = ((long)1 * NL + m) * g.G + o, iD = ((long)2 * NL + m) * g.G + o;
+    out[iH] = in_x ? yH[m] - (rl ? rl[iH] : 0.0) : 0.0;
+    out[iV] = in_y ? yV[m] - (rl ? rl[iV] : 0.0) : 0.0;
+    out[iD] = (in_x && in_y) ? yD[m] - (rl ? rl[iD] : 0.0) : 0.0;
+  }
+}
+
+// K8  local back-substitution:  (u, phi)_K = Ainv r_{x,K} - W lambda_K
+template <int K, bool HASW, bool HASP>
+__global__ __launch_bounds__(128) void k_backsub(Geo g, DevTables T, const double* __restrict__ rw,
+                                                  const double* __restrict__ rp, const double* __restrict__ lam,
+                                                  double* __restrict__ u, double* __restrict__ phi) {
+  constexpr int NU = Dim<K>::NU, NP = Dim<K>::NP, NL = Dim<K>::NL, NX = Dim<K>::NX, NT = 3 * NL, N2 = 2 * NU;
+  HDG_CELL_PROLOGUE
+  double y[NX];
+#pragma unroll
+  for (int n = 0; n < NX; n++) y[n] = 0.0;
+  const double* __restrict__ Ai = T.Ainv[s];
+  if (HASW) {
+    double x[N2];
+    load_cell<N2>(rw, g.Nc, c, x);
+    mv_acc_ld<NX, N2>(Ai, NX, x, y, 1.0);
+  }
+  if (HASP) {
+    double x[NP];
+    load_cell<NP>(rp, g.Nc, c, x);
+    mv_acc_ld<NX, NP>(Ai + N2, NX, x, y, 1.0);
+  }
+  double l[NT];
+#pragma unroll
+  for (int e = 0; e < 3; e++) {
+    int t;
+    const long off = edge_off(s, e, i, j, g, t);
+    load_tr<NL>(lam, g, t, off, l + e * NL);
+  }
+  mv_acc_ld<NX, NT>(T.W[s], NT, l, y, -1.0);
+#pragma unroll
+  for (int n = 0; n < N2; n++) u[(long)n * g.Nc + c] = y[n];
+#pragma unroll
+  for (int n = 0; n < NP; n++) phi[(long)n * g.Nc + c] = y[N2 + n];
+}
+
+// trace reconstruction (hdg_imex.py:450-469):
+//   interior: lambda = {{p}} + (Q+.n+ + Q-.n-)/(2 tau);  boundary: lambda = p + Q.n/tau   (L2 on P_k(e))
+template <int K>
+__device__ __forceinline__ void trace_side(const DevTables& T, int s, int e, const double* __restrict__ Q,
+                                           const double* __restrict__ p, long Nc, long c, double wq, double wp,
+                                           double* acc) {
+  constexpr int NU = Dim<K>::NU, NP = Dim<K>::NP, NL = Dim<K>::NL, N2 = 2 * NU;
+  double x[N2], pp[NP];
+  load_cell<N2>(Q, Nc, c, x);
+  load_cell<NP>(p, Nc, c, pp);
+  mv_acc_ld<NL, N2>(T.N[s][e], N2, x, acc, wq * T.sig[s][e]);
+  mv_acc_ld<NL, NP>(T.Pt[s][e], NP, pp, acc, wp);
+}
+
+template <int K>
+__global__ __launch_bounds__(128) void k_trace_recon(Geo g, DevTables T, const double* __restrict__ Q,
+                                                      const double* __restrict__ p, double* __restrict__ out) {
+  constexpr int NL = Dim<K>::NL;
+  HDG_CORNER_PROLOGUE
+  const long nxy = (long)g.nx * g.ny;
+  const double it = 1.0 / T.tau;
+#pragma unroll
+  for (int t = 0; t < 3; t++) {
+    const int e = (t == 0) ? 0 : (t == 1 ? 2 : 1);
+    bool valid, hasL, hasU;
+    long cL, cU;
+    if (t == 0) { valid = in_x; hasL = in_y; hasU = j > 0; cL = (long)j * g.nx + i; cU = nxy + (long)(j - 1) * g.nx + i; }
+    else if (t == 1) { valid = in_y; hasL = in_x; hasU = i > 0; cL = (long)j * g.nx + i; cU = nxy + (long)j * g.nx + i - 1; }
+    else { valid = in_x && in_y; hasL = hasU = true; cL = (long)j * g.nx + i; cU = nxy + cL; }
+    double acc[NL];
+#pragma unroll
+    for (int m = 0; m < NL; m++) acc[m] = 0.0;
+    if (valid) {
+      const double w = (hasL && hasU) ? 0.5 : 1.0;
+      if (hasL) trace_side<K>(T, 0, e, Q, p, g.Nc, cL, w * it, w, acc);
+      if (hasU) trace_side<K>(T, 1, e, Q, p, g.Nc, cU, w * it, w, acc);
+    }
+#pragma unroll
+    for (int m = 0; m < NL; m++) out[((long)t * NL + m) * g.G + o] = acc[m];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// pressure-reconstruction right-hand side (hdg_imex.py:201-207):
+//   rp = weak_divergence(psi, v),  v = -b + (Q.grad)Q  (per cell: -(grad psi, v)_K + <psi,{{v}}.n>_int)
+//   rl = - int_{dOmega} mu n.b    (boundary edges only; interior entries zero)
+// ------------------------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(128) void k_precon_rhs(Geo g, DevTables T, const double* __restrict__ Q,
+                                                     const double* __restrict__ bnew, double bscale,
+                                                     double* __restrict__ rp, double* __restrict__ rl) {
+  constexpr int NU = Dim<K>::NU, NP = Dim<K>::NP, NL = Dim<K>::NL, N2 = 2 * NU;
+  HDG_CELL_PROLOGUE
+  double x[N2], b[N2], y[NP];
+  load_cell<N2>(Q, g.Nc, c, x);
+  load_cell<N2>(bnew, g.Nc, c, b);
+#pragma unroll
+  for (int n = 0; n < N2; n++) b[n] *= bscale;
+#pragma unroll
+  for (int r = 0; r < NP; r++) y[r] = 0.0;
+  {
+    const double* __restrict__ Phi = T.cPhi[s];
+    const double* __restrict__ Gx = T.cGx[s];
+    const double* __restrict__ Gy = T.cGy[s];
+#pragma unroll 1
+    for (int q = 0; q < T.nqc; q++) {
+      double qx = 0, qy = 0, bx = 0, by = 0, dxx = 0, dxy = 0, dyx = 0, dyy = 0;
+#pragma unroll
+      for (int m = 0; m < NU; m++) {
+        const double ph = Phi[q * NU + m], gx = Gx[q * NU + m], gy = Gy[q * NU + m];
+        qx = fma(ph, x[m], qx); qy = fma(ph, x[NU + m], qy);
+        bx = fma(ph, b[m], bx); by = fma(ph, b[NU + m], by);
+        dxx = fma(gx, x[m], dxx); dxy = fma(gy, x[m], dxy);
+        dyx = fma(gx, x[NU + m], dyx); dyy = fma(gy, x[NU + m], dyy);
+      }
+      const double w = T.cw[q];
+      const double vx = -bx + qx * dxx + qy * dxy, vy = -by + qx * dyx + qy * dyy;
+#pragma unroll
+      for (int r = 0; r < NP; r++) y[r] -= w * (Gx[q * NU + r] * vx + Gy[q * NU + r] * vy);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 3; e++) {
+    long cn;
+    const bool has = nbr(s, e, i, j, g, cn);
+    const double nx_ = T.enx[e], ny_ = T.eny[e], sg = T.sig[s][e];
+    if (has) {
+      double xn[N2], bn[N2];
+      load_cell<N2>(Q, g.Nc, cn, xn);
+      load_cell<N2>(bnew, g.Nc, cn, bn);
+      const double* __restrict__ Po = T.ePhi[s][e];
+      const double* __restrict__ Gxo = T.eGx[s][e];
+      const double* __restrict__ Gyo = T.eGy[s][e];
+      const double* __restrict__ Pn = T.ePhi[1 - s][e];
+      const double* __restrict__ Gxn = T.eGx[1 - s][e];
+      const double* __restrict__ Gyn = T.eGy[1 - s][e];
+#pragma unroll 1
+      for (int q = 0; q < T.nqe; q++) {
+        double vn = 0.0;
+        {
+          double qx = 0, qy = 0, bx = 0, by = 0, dxx = 0, dxy = 0, dyx = 0, dyy = 0;
+#pragma unroll
+          for (int m = 0; m < NU; m++) {
+            const double ph = Po[q * NU + m], gx = Gxo[q * NU + m], gy = Gyo[q * NU + m];
+            qx = fma(ph, x[m], qx); qy = fma(ph, x[NU + m], qy);
+            bx = fma(ph, b[m], bx); by = fma(ph, b[NU + m], by);
+            dxx = fma(gx, x[m], dxx); dxy = fma(gy, x[m], dxy);
+            dyx = fma(gx, x[NU + m], dyx); dyy = fma(gy, x[NU + m], dyy);
+          }
+          vn += 0.5 * ((-bx + qx * dxx + qy * dxy) * nx_ + (-by + qx * dyx + qy * dyy) * ny_);
+        }
+        {
+          double qx = 0, qy = 0, bx = 0, by = 0, dxx = 0, dxy = 0, dyx = 0, dyy = 0;
+#pragma unroll
+          for (int m = 0; m < NU; m++) {
+            const double ph = Pn[q * NU + m], gx = Gxn[q * NU + m], gy = Gyn[q * NU + m];
+            qx = fma(ph, xn[m], qx); qy = fma(ph, xn[NU + m], qy);
+            bx = fma(ph, bscale * bn[m], bx); by = fma(ph, bscale * bn[NU + m], by);
+            dxx = fma(gx, xn[m], dxx); dxy = fma(gy, xn[m], dxy);
+            dyx = fma(gx, xn[NU + m], dyx); dyy = fma(gy, xn[NU + m], dyy);
+          }
+          vn += 0.5 * ((-bx + qx * dxx + qy * dxy) * nx_ + (-by + qx * dyx + qy * dyy) * ny_);
+        }
+        const double w = T.ew[e][q] * sg * vn;
+#pragma unroll
+        for (int r = 0; r < NP; r++) y[r] = fma(Po[q * NU + r], w, y[r]);
+      }
+    } else {
+      // boundary edge: rl = - <mu, n_K . b> = - sigma * (N_e b)[0:NL]
+      double tr[NL];
+#pragma unroll
+      for (int m = 0; m < NL; m++) tr[m] = 0.0;
+      mv_acc_ld<NL, N2>(T.N[s][e], N2, b, tr, -sg);
+      int t;
+      const long off = edge_off(s, e, i, j, g, t);
+#pragma unroll
+      for (int m = 0; m < NL; m++) rl[((long)t * NL + m) * g.G + off] = tr[m];
+    }
+  }
+  store_cell<NP>(rp, g.Nc, c, y);
+}
+
+// ------------------------------------------------------------------------------------------
+// nodal <-> modal conversion at the library boundary (array-of-structures, reference layout)
+// ------------------------------------------------------------------------------------------
+// velocity: nodal[(cref*NU + node)*2 + d], cref = 2*(j*nx+i)+s
+template <int K>
+__global__ void k_q_nodal_to_modal(Geo g, DevTables T, const double* __restrict__ nodal, double* __restrict__ modal) {
+  constexpr int NU = Dim<K>::NU;
+  HDG_CELL_PROLOGUE
+  const long cref = 2 * ((long)j * g.nx + i) + s;
+#pragma unroll 1
+  for (int d = 0; d < 2; d++) {
+    double v[NU], m[NU];
+#pragma unroll
+    for (int n = 0; n < NU; n++) { v[n] = nodal[(cref * NU + n) * 2 + d]; m[n] = 0.0; }
+    mv_acc<NU, NU>(T.Vuinv, v, m, 1.0);
+#pragma unroll
+    for (int n = 0; n < NU; n++) modal[((long)d * NU + n) * g.Nc + c] = m[n];
+  }
+}
+template <int K>
+__global__ void k_q_modal_to_nodal(Geo g, DevTables T, const double* __restrict__ modal, double* __restrict__ nodal) {
+  constexpr int NU = Dim<K>::NU;
+  HDG_CELL_PROLOGUE
+  const long cref = 2 * ((long)j * g.nx + i) + s;
+#pragma unroll 1
+  for (int d = 0; d < 2; d++) {
+    double v[NU], m[NU];
+#pragma unroll
+    for (int n = 0; n < NU; n++) { m[n] = modal[((long)d * NU + n) * g.Nc + c]; v[n] = 0.0; }
+    mv_acc<NU, NU>(T.Vu, m, v, 1.0);
+#pragma unroll
+    for (int n = 0; n < NU; n++) nodal[(cref * NU + n) * 2 + d] = v[n];
+  }
+}
+template <int K>
+__global__ void k_p_nodal_to_modal(Geo g, DevTables T, const double* __restrict__ nodal, double* __restrict__ modal) {
+  constexpr int NP = Dim<K>::NP;
+  HDG_CELL_PROLOGUE
+  const long cref = 2 * ((long)j * g.nx + i) + s;
+  double v[NP], m[NP];
+#pragma unroll
+  for (int n = 0; n < NP; n++) { v[n] = nodal[cref * NP + n]; m[n] = 0.0; }
+  mv_acc<NP, NP>(T.Vpinv, v, m, 1.0);
+  store_cell<NP>(modal, g.Nc, c, m);
+}
+template <int K>
+__global__ void k_p_modal_to_nodal(Geo g, DevTables T, const double* __restrict__ modal, double* __restrict__ nodal) {
+  constexpr int NP = Dim<K>::NP;
+  HDG_CELL_PROLOGUE
+  const long cref = 2 * ((long)j * g.nx + i) + s;
+  double v[NP], m[NP];
+  load_cell<NP>(modal, g.Nc, c, m);
+#pragma unroll
+  for (int n = 0; n < NP; n++) v[n] = 0.0;
+  mv_acc<NP, NP>(T.Vp, m, v, 1.0);
+#pragma unroll
+  for (int n = 0; n < NP; n++) nodal[cref * NP + n] = v[n];
+}
+// trace: nodal[e*NL + node], edge numbering of oracle/fem.py; modal basis chi_a = Leg_a / sqrt(len)
+template <int K, bool TO_MODAL>
+__global__ void k_l_convert(Geo g, DevTables T, double* __restrict__ nodal, double* __restrict__ modal) {
+  constexpr int NL = Dim<K>::NL;
+  HDG_CORNER_PROLOGUE
+  const long NH = (long)g.nx * (g.ny + 1), NV = (long)(g.nx + 1) * g.ny;
+#pragma unroll
+  for (int t = 0; t < 3; t++) {
+    bool valid;
+    long eidx;
+    double len;
+    if (t == 0) { valid = in_x; eidx = (long)j * g.nx + i; len = T.elen[0]; }
+    else if (t == 1) { valid = in_y; eidx = NH + (long)j * (g.nx + 1) + i; len = T.elen[2]; }
+    else { valid = in_x && in_y; eidx = NH + NV + (long)j * g.nx + i; len = T.elen[1]; }
+    if (!valid) continue;
+    double a[NL], b[NL];
+    if (TO_MODAL) {
+#pragma unroll
+      for (int m = 0; m < NL; m++) { a[m] = nodal[eidx * NL + m]; b[m] = 0.0; }
+      mv_acc<NL, NL>(T.Vlinv, a, b, sqrt(len));
+#pragma unroll
+      for (int m = 0; m < NL; m++) modal[((long)t * NL + m) * g.G + o] = b[m];
+    } else {
+#pragma unroll
+      for (int m = 0; m < NL; m++) { a[m] = modal[((long)t * NL + m) * g.G + o]; b[m] = 0.0; }
+      mv_acc<NL, NL>(T.Vl, a, b, 1.0 / sqrt(len));
+#pragma unroll
+      for (int m = 0; m < NL; m++) nodal[eidx * NL + m] = b[m];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// vector kernels (grid-stride, 2 doubles per lane per access)
+// ------------------------------------------------------------------------------------------
+struct LinComb {
+  const double* v[8];
+  double c[8];
+  int n;
+};
+__global__ void k_lincomb(long N, LinComb lc, double* __restrict__ out) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < N; idx += stride) {
+    double acc = 0.0;
+    for (int k = 0; k < lc.n; k++) acc = fma(lc.c[k], lc.v[k][idx], acc);
+    out[idx] = acc;
+  }
+}
+// y = a*x + b*y
+__global__ void k_axpby(long N, double a, const double* __restrict__ x, double b, double* __restrict__ y) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < N; idx += stride)
+    y[idx] = (b == 0.0) ? a * x[idx] : fma(a, x[idx], b * y[idx]);
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// partial dots of w against nv vectors V[k] (k < nv <= MAXV): part[block*nv + k]; deterministic
+#define HDG_DOT_BLOCK 256
+template <int MAXV>
+__global__ __launch_bounds__(HDG_DOT_BLOCK) void k_multidot(long N, const double* __restrict__ w,
+                                                             const double* const* __restrict__ V, int nv,
+                                                             double* __restrict__ part) {
+  __shared__ double sm[HDG_DOT_BLOCK / 64][MAXV];
+  double acc[MAXV];
+#pragma unroll
+  for (int k = 0; k < MAXV; k++) acc[k] = 0.0;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < N; idx += stride) {
+    const double wv = w[idx];
+#pragma unroll
+    for (int k = 0; k < MAXV; k++)
+      if (k < nv) acc[k] = fma(wv, V[k][idx], acc[k]);
+  }
+  const int lane = threadIdx.x & 63, wv_ = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < MAXV; k++) {
+    if (k < nv) {
+      const double s = wave_sum(acc[k]);
+      if (lane == 0) sm[wv_][k] = s;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < nv) {
+    double s = 0.0;
+    for (int w2 = 0; w2 < HDG_DOT_BLOCK / 64; w2++) s += sm[w2][threadIdx.x];
+    part[(long)blockIdx.x * nv + threadIdx.x] = s;
+  }
+}
+__global__ void k_reduce_parts(int nblocks, int nv, const double* __restrict__ part, double* __restrict__ res) {
+  const int k = blockIdx.x;
+  double acc = 0.0;
+  for (int b = threadIdx.x; b < nblocks; b += blockDim.x) acc += part[(long)b * nv + k];
+  __shared__ double sm[4];
+  const double s = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double tot = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); w++) tot += sm[w];
+    res[k] = tot;
+  }
+}
+// w -= sum_k h[k] V[k]
+template <int MAXV>
+__global__ void k_multiaxpy(long N, double* __restrict__ w, const double* const* __restrict__ V,
+                            const double* __restrict__ hcoef, int nv, double sign) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < N; idx += stride) {
+    double acc = w[idx];
+#pragma unroll
+    for (int k = 0; k < MAXV; k++)
+      if (k < nv) acc = fma(sign * hcoef[k], V[k][idx], acc);
+    w[idx] = acc;
+  }
+}
+
+// pressure / trace mean shift (hdg_imex.py:471-478): p -= pbar, lambda -= pbar (modal mode 0 only)
+__global__ void k_shift_p(long Nc, double* __restrict__ p, const double* __restrict__ sum0, double factor, double c0) {
+  // pbar = factor * sum0[0];  p_{K,0} -= pbar * c0
+  const double pbar = factor * sum0[0];
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < Nc; idx += stride) p[idx] -= pbar * c0;
+}
+__global__ void k_shift_l(Geo g, int NL, double* __restrict__ l, const double* __restrict__ sum0, double factor,
+                          double sH, double sV, double sD) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y;
+  if (i > g.nx) return;
+  const double pbar = factor * sum0[0];
+  const long o = (long)j * g.P + i;
+  const bool in_x = i < g.nx, in_y = j < g.ny;
+  if (in_x) l[((long)0 * NL) * g.G + o] -= pbar * sH;
+  if (in_y) l[((long)1 * NL) * g.G + o] -= pbar * sV;
+  if (in_x && in_y) l[((long)2 * NL) * g.G + o] -= pbar * sD;
+}
+
+// ------------------------------------------------------------------------------------------
+// geometric multigrid on the P1 vertex grid (coarse space of the GTMG preconditioner,
+// hdg_imex.py:97-118,139-167).  Vertex (i,j) of an (n+1)x(n+1) grid at index j*(n+1)+i.
+// Operator: P1 stiffness matrix of the right-triangle mesh = 5-point Laplacian with
+// half weights along boundary edges (homogeneous Neumann).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void p1_stencil(const double* __restrict__ x, int n, int i, int j, double& diag, double& off) {
+  const int st = n + 1;
+  const double wx = (j == 0 || j == n) ? 0.5 : 1.0;  // weight of horizontal edges in this row
+  const double wy = (i == 0 || i == n) ? 0.5 : 1.0;
+  diag = 0.0;
+  off = 0.0;
+  if (i > 0) { diag += wx; off += wx * x[j * st + i - 1]; }
+  if (i < n) { diag += wx; off += wx * x[j * st + i + 1]; }
+  if (j > 0) { diag += wy; off += wy * x[(j - 1) * st + i]; }
+  if (j < n) { diag += wy; off += wy * x[(j + 1) * st + i]; }
+}
+// red-black Gauss-Seidel half sweep on A x = b
+__global__ void k_p1_rbgs(int n, double* __restrict__ x, const double* __restrict__ b, int colour) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
+  if (i > n || ((i + j) & 1) != colour) return;
+  double diag, off;
+  p1_stencil(x, n, i, j, diag, off);
+  x[j * (n + 1) + i] = (b[j * (n + 1) + i] + off) / diag;
+}
+__global__ void k_p1_residual(int n, const double* __restrict__ x, const double* __restrict__ b, double* __restrict__ r) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
+  if (i > n) return;
+  double diag, off;
+  p1_stencil(x, n, i, j, diag, off);
+  r[j * (n + 1) + i] = b[j * (n + 1) + i] - (diag * x[j * (n + 1) + i] - off);
+}
+// restriction = transpose of nested P1 interpolation (coarse diagonal joins (I+1,J) and (I,J+1))
+__global__ void k_p1_restrict(int nc, const double* __restrict__ rf, double* __restrict__ rc) {
+  const int I = blockIdx.x * blockDim.x + threadIdx.x, J = blockIdx.y;
+  if (I > nc) return;
+  const int nf = 2 * nc, st = nf + 1, i = 2 * I, j = 2 * J;
+  double acc = rf[j * st + i];
+  if (i > 0) acc += 0.5 * rf[j * st + i - 1];
+  if (i < nf) acc += 0.5 * rf[j * st + i + 1];
+  if (j > 0) acc += 0.5 * rf[(j - 1) * st + i];
+  if (j < nf) acc += 0.5 * rf[(j + 1) * st + i];
+  if (i > 0 && j < nf) acc += 0.5 * rf[(j + 1) * st + i - 1];
+  if (i < nf && j > 0) acc += 0.5 * rf[(j - 1) * st + i + 1];
+  rc[J * (nc + 1) + I] = acc;
+}
+__global__ void k_p1_prolong_add(int nc, const double* __restrict__ xc, double* __restrict__ xf) {
+  const int nf = 2 * nc;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
+  if (i > nf) return;
+  const int I = i >> 1, J = j >> 1, sc = nc + 1;
+  double v;
+  if (!(i & 1) && !(j & 1)) v = xc[J * sc + I];
+  else if ((i & 1) && !(j & 1)) v = 0.5 * (xc[J * sc + I] + xc[J * sc + I + 1]);
+  else if (!(i & 1) && (j & 1)) v = 0.5 * (xc[J * sc + I] + xc[(J + 1) * sc + I]);
+  else v = 0.5 * (xc[J * sc + I + 1] + xc[(J + 1) * sc + I]);
+  xf[j * (nf + 1) + i] += v;
+}
+__global__ void k_fill(long N, double* __restrict__ x, double v) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < N; idx += stride) x[idx] = v;
+}
+
+// trace <-> P1 transfer: P = edge-wise L2 projection of the P1 function (hdg_imex.py:491-503,
+// without the reference's 1/2 on interior edges - a preconditioner detail)
+__global__ void k_p1_to_trace(Geo g, int NL, const double* __restrict__ xc, double* __restrict__ l, double accumulate,
+                              double lH, double lV, double lD) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
+  if (i > g.nx) return;
+  const long o = (long)j * g.P + i;
+  const int st = g.nx + 1;
+  const bool in_x = i < g.nx, in_y = j < g.ny;
+  const double r3 = 0.57735026918962576451;
+  const double v00 = xc[j * st + i];
+  if (in_x) {
+    const double vb = xc[j * st + i + 1], sl = sqrt(lH);
+    double* p0 = l + ((long)0 * NL) * g.G + o;
+    double* p1 = l + ((long)0 * NL + 1) * g.G + o;
+    *p0 = accumulate * (*p0) + sl * 0.5 * (v00 + vb);
+    *p1 = accumulate * (*p1) + sl * r3 * 0.5 * (vb - v00);
+  }
+  if (in_y) {
+    const double vb = xc[(j + 1) * st + i], sl = sqrt(lV);
+    double* p0 = l + ((long)1 * NL) * g.G + o;
+    double* p1 = l + ((long)1 * NL + 1) * g.G + o;
+    *p0 = accumulate * (*p0) + sl * 0.5 * (v00 + vb);
+    *p1 = accumulate * (*p1) + sl * r3 * 0.5 * (vb - v00);
+  }
+  if (in_x && in_y) {
+    const double va = xc[j * st + i + 1], vb = xc[(j + 1) * st + i], sl = sqrt(lD);
+    double* p0 = l + ((long)2 * NL) * g.G + o;
+    double* p1 = l + ((long)2 * NL + 1) * g.G + o;
+    *p0 = accumulate * (*p0) + sl * 0.5 * (va + vb);
+    *p1 = accumulate * (*p1) + sl * r3 * 0.5 * (vb - va);
+  }
+}
+// transpose: vertex gathers from its (up to six) incident edges
+__global__ void k_trace_to_p1(Geo g, int NL, const double* __restrict__ l, double* __restrict__ rc, double lH, double lV,
+                              double lD) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
+  if (i > g.nx) return;
+  const int st = g.nx + 1;
+  const double r3 = 0.57735026918962576451;
+  const double* H0 = l + ((long)0 * NL) * g.G;
+  const double* H1 = l + ((long)0 * NL + 1) * g.G;
+  const double* V0 = l + ((long)1 * NL) * g.G;
+  const double* V1 = l + ((long)1 * NL + 1) * g.G;
+  const double* D0 = l + ((long)2 * NL) * g.G;
+  const double* D1 = l + ((long)2 * NL + 1) * g.G;
+  const long o = (long)j * g.P + i;
+  const double sH = 0.5 * sqrt(lH), sV = 0.5 * sqrt(lV), sD = 0.5 * sqrt(lD);
+  double acc = 0.0;
+  if (i < g.nx) acc += sH * (H0[o] - r3 * H1[o]);                              // H(i,j): a-end
+  if (i > 0) acc += sH * (H0[o - 1] + r3 * H1[o - 1]);                         // H(i-1,j): b-end
+  if (j < g.ny) acc += sV * (V0[o] - r3 * V1[o]);                              // V(i,j): a-end
+  if (j > 0) acc += sV * (V0[o - g.P] + r3 * V1[o - g.P]);                     // V(i,j-1): b-end
+  if (i > 0 && j < g.ny) acc += sD * (D0[o - 1] - r3 * D1[o - 1]);             // D(i-1,j): a-end (x_{i},y_j)
+  if (i < g.nx && j > 0) acc += sD * (D0[o - g.P] + r3 * D1[o - g.P]);         // D(i,j-1): b-end (x_i,y_j)
+  rc[j * st + i] = acc;
+}
+
+}  // namespace hdg
