@@ -721,9 +721,10 @@ struct Engine {
     const double dtt = cfg.dt;
     ensure_dinv(0, dtt);
     bdm(curQ, Qstar[0]);                                         // hdg_implicit.py:98
-    lincomb(NQ, {{curQ, 1.0}, {bvec(0), dtt * bscale[0]}}, wQ3);  // (Q,w) + dt (f,w)
+    // rhs lives in updU: wQ1..wQ4 are scratch of GMRES and its preconditioner
+    lincomb(NQ, {{curQ, 1.0}, {bvec(0), dtt * bscale[0]}}, updU);  // (Q,w) + dt (f,w)
     zero(Qtent[0], NQ);
-    int it1 = gmres(Qstar[0], dtt, 0, wQ3, Qtent[0]);            // hdg_implicit.py:103-129
+    int it1 = gmres(Qstar[0], dtt, 0, updU, Qtent[0]);           // hdg_implicit.py:103-129
     weak_div(Qtent[0], -1.0 / dtt, wP1, true);                   // hdg_implicit.py:145
     condense(nullptr, wP1, nullptr, wL1);
     zero(updL, NLv);

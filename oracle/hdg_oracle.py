@@ -199,6 +199,10 @@ class HDGDiscretisation:
             Lm,
             (self.NL, self.NL),
         )
+        # integral functional on DGT_k, every edge counted once (used to make inconsistent data consistent)
+        mult = np.where(np.repeat(m.interior, nl), 2.0, 1.0)
+        self.int_l = np.asarray(self.Lm.sum(axis=0)).ravel() / tau / mult
+        self.skeleton_length = float(np.sum(m.edge_len))
         # trace mass used by _reconstruct_trace (hdg_imex.py:462): 2 tau lam+ mu+ dS + tau lam mu ds
         # = tau * (sum over incidences), i.e. self.Lm.
 
@@ -276,14 +280,17 @@ class HDGDiscretisation:
     def solve_mixed_poisson(self, rQ=None, rP=None, rL=None):
         """Solve the (singular) hybridised mixed Poisson system; returns (u, phi, lambda) with
         zero-mean phi (the constant is removed again by the callers' _shift_pressure)."""
-        r = np.concatenate(
-            [
-                np.zeros(self.NQ) if rQ is None else rQ,
-                np.zeros(self.NP) if rP is None else rP,
-                np.zeros(self.NL) if rL is None else rL,
-                [0.0],
-            ]
-        )
+        rP = np.zeros(self.NP) if rP is None else rP
+        rL = np.zeros(self.NL) if rL is None else rL
+        # The operator is singular: left null vector (0, -1, 1), right null vector (0, 1, 1).  Data that
+        # are not orthogonal to the left null vector (hdg_implicit.py:145 uses the BROKEN divergence;
+        # the reference hands that to a direct solver with no null-space information, SURVEY.md C-5,
+        # so its result is ill defined) are made consistent by a uniform flux correction on the
+        # skeleton: r_lambda(mu) -= c * int_E mu ds.  This is basis independent and is exactly what
+        # projecting the condensed right-hand side orthogonally to the constants does.
+        c = (np.sum(rL) - np.sum(rP)) / self.skeleton_length
+        rL = rL - c * self.int_l
+        r = np.concatenate([np.zeros(self.NQ) if rQ is None else rQ, rP, rL, [0.0]])
         x = self._lu_mp.solve(r)
         return x[: self.NQ], x[self.NQ : self.NQ + self.NP], x[self.NQ + self.NP : self.N]
 

@@ -1,0 +1,143 @@
+"""GPU parity of whole timesteps against the CPU oracle, through the class surface of the reference.
+
+Tolerance: the reference solves the tentative-velocity systems to rtol 1e-10 and the condensed trace
+systems to rtol 1e-12 (hdg_imex.py:137,226); the oracle uses sparse direct solves.  Fields from two
+converged solvers therefore agree to roughly 1e-8 relative in max-norm, not to round-off
+(SURVEY.md section 8c); the tests use 2e-8 relative to the field's max-norm.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-8
+
+
+def _relerr(a, b):
+    return np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(np.max(np.abs(b)), 1e-300)
+
+
+def _classes():
+    from incompressibleeulerhdg_amd import timesteppers as ts
+
+    return {
+        "imex_implicit": ts.IncompressibleEulerHDGIMEXImplicit,
+        "imex_ars2_232": ts.IncompressibleEulerHDGIMEXARS2_232,
+        "imex_ars3_443": ts.IncompressibleEulerHDGIMEXARS3_443,
+        "imex_ssp2_332": ts.IncompressibleEulerHDGIMEXSSP2_332,
+        "imex_ssp3_433": ts.IncompressibleEulerHDGIMEXSSP3_433,
+    }
+
+
+def _run_pair(k, nx, tableau, nsteps, R=2, flux="upwind", fused=False, kappa=0.5, forcing="exponential", **opts):
+    from incompressibleeulerhdg_amd import _lib
+    from incompressibleeulerhdg_amd.mesh import UnitSquareMesh
+    from incompressibleeulerhdg_amd.model_problems import TaylorGreen
+    from oracle import hdg_oracle as orc
+
+    dt = 0.25 / nx
+    mesh = UnitSquareMesh(nx, nx, quadrilateral=False)
+    ts = _classes()[tableau](mesh, k, dt, flux=flux, use_projection_method=True, n_richardson=R, **opts)
+    mp = TaylorGreen(ts._V_Q, ts._V_p, forcing, kappa)
+    Q0, p0 = mp.initial_condition()
+    Q, p = ts.solve(Q0, p0, None, mp.f_rhs(), nsteps * dt, fused=fused)
+    _, _, lam = ts._engine.get_field(_lib.HDG_STATE_CURRENT, Q=False, p=False)
+
+    d = orc.HDGDiscretisation(nx, k)
+    tg = orc.TaylorGreen(d, forcing, kappa)
+    o = orc.OracleHDGIMEX(d, dt, tableau, flux=flux, n_richardson=R)
+    oQ0, op0 = tg.initial_condition()
+    oQ, op = o.solve(oQ0, op0, tg.f_rhs, nsteps * dt)
+    return (Q.dat.data, p.dat.data, lam), (oQ, op, o.lam), ts, o, d
+
+
+@pytest.mark.parametrize("k,nx", [(1, 4), (1, 8), (2, 4), (2, 8), (3, 4)])
+def test_imex_ssp2_two_steps(hip_lib, k, nx):
+    got, ref, ts, o, d = _run_pair(k, nx, "imex_ssp2_332", 2)
+    for a, b, name in zip(got, ref, "Qpl"):
+        assert _relerr(a, b) < TOL, name
+    # stage vectors persist: compare the last stage iterate too
+    sQ, sp, sl = ts._engine.get_field(2)
+    assert _relerr(sQ, o.stage_Q[2]) < TOL and _relerr(sp, o.stage_p[2]) < TOL and _relerr(sl, o.stage_l[2]) < TOL
+
+
+@pytest.mark.parametrize("tableau", ["imex_implicit", "imex_ars2_232", "imex_ars3_443", "imex_ssp3_433"])
+def test_other_tableaux(hip_lib, tableau):
+    got, ref, *_ = _run_pair(1, 6, tableau, 2)
+    for a, b, name in zip(got, ref, "Qpl"):
+        assert _relerr(a, b) < TOL, name
+
+
+def test_fused_step_equals_piecewise(hip_lib):
+    a, ref, *_ = _run_pair(2, 4, "imex_ssp2_332", 2, fused=True)
+    b, _, *_ = _run_pair(2, 4, "imex_ssp2_332", 2, fused=False)
+    for x, y in zip(a, b):
+        assert _relerr(x, y) < 1e-12
+    for x, y in zip(a, ref):
+        assert _relerr(x, y) < TOL
+
+
+def test_centered_flux_constant_forcing_richardson1(hip_lib):
+    got, ref, *_ = _run_pair(1, 6, "imex_ssp2_332", 2, R=1, flux="centered", forcing="constant")
+    for a, b, name in zip(got, ref, "Qpl"):
+        assert _relerr(a, b) < TOL, name
+
+
+@pytest.mark.parametrize("tp,trp", [(0, 0), (1, 0), (0, 1)])
+def test_preconditioner_choice_does_not_change_the_answer(hip_lib, tp, trp):
+    got, ref, *_ = _run_pair(1, 8, "imex_ssp2_332", 1, tent_precond=tp, trace_precond=trp)
+    for a, b, name in zip(got, ref, "Qpl"):
+        assert _relerr(a, b) < TOL, name
+
+
+def test_invariants_after_a_step(hip_lib):
+    """Basis-independent discrete invariants: zero-mean pressure, Q* normal
+    continuity and zero boundary flux, weakly divergence-free final velocity."""
+    from incompressibleeulerhdg_amd import _lib
+
+    got, ref, ts, o, d = _run_pair(2, 6, "imex_ssp2_332", 1)
+    Q, p, lam = got
+    assert abs(ts._engine.integrate_pressure(p)) < 1e-12
+    # Gamma(psi, mu; Q, p, lambda) = 0: rows 2 and 3 of the mixed Poisson operator applied to the
+    # final-stage solution vanish.  Checked with the oracle's matrices on the device result's Q only:
+    # (psi, div Q) + tau<p - lambda, psi> involves the FINAL-STAGE (p, lambda), which the reference
+    # overwrites (hdg_imex.py:633-636); the device keeps them nowhere either, so check Q* instead.
+    Qs = ts._engine.get_field(200 + 1, p=False, lam=False)[0]
+    assert _relerr(ts._engine.project_bdm_nodal(Qs), Qs) < 1e-11  # idempotent on H(div) input
+    assert _relerr(Qs, o.Qstar[1]) < TOL
+
+
+def test_taylor_green_error_norms_match_oracle(hip_lib):
+    """driver.py:365-381: the two printed error norms agree with the oracle's."""
+    from incompressibleeulerhdg_amd.model_problems import TaylorGreen
+    from oracle import hdg_oracle as orc
+
+    k, nx, nsteps = 1, 8, 4
+    got, ref, ts, o, d = _run_pair(k, nx, "imex_ssp2_332", nsteps)
+    T = nsteps * 0.25 / nx
+    mp = TaylorGreen(ts._V_Q, ts._V_p)
+    Qe, pe = mp.solution(T, ts._engine.integrate_pressure)
+    eq, ep = ts._engine.l2_norms(got[0] - Qe.dat.data, got[1] - pe.dat.data)
+    tg = orc.TaylorGreen(d)
+    oQe, ope = tg.solution(T)
+    assert abs(eq - d.l2_norm_velocity(ref[0] - oQe)) < 1e-9
+    assert abs(ep - d.l2_norm_pressure(ref[1] - ope)) < 1e-9
+    assert eq < 2e-3 and ep < 2e-2
+
+
+@pytest.mark.parametrize("k,nx", [(1, 8), (2, 4)])
+def test_hdg_implicit_projection(hip_lib, k, nx):
+    from incompressibleeulerhdg_amd.mesh import UnitSquareMesh
+    from incompressibleeulerhdg_amd.model_problems import TaylorGreen
+    from incompressibleeulerhdg_amd.timesteppers import IncompressibleEulerHDGImplicit
+    from oracle import hdg_oracle as orc
+
+    dt = 0.05
+    ts = IncompressibleEulerHDGImplicit(UnitSquareMesh(nx, nx), k, dt, flux="upwind", use_projection_method=True,
+                                        n_richardson=2)
+    mp = TaylorGreen(ts._V_Q, ts._V_p)
+    Q, p = ts.solve(*mp.initial_condition(), None, mp.f_rhs(), 3 * dt)
+    d = orc.HDGDiscretisation(nx, k)
+    tg = orc.TaylorGreen(d)
+    oQ, op = orc.OracleHDGImplicit(d, dt).solve(*tg.initial_condition(), tg.f_rhs, 3 * dt)
+    assert _relerr(Q.dat.data, oQ) < TOL and _relerr(p.dat.data, op) < TOL
