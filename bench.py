@@ -1,0 +1,182 @@
+#!/usr/bin/env python
+"""Headline benchmark: million DOF-updates/s of the HDG-IMEX timestep (BASELINE.json).
+
+A "step" is one HDG-IMEX SSP2(3,3,2) timestep (2 Richardson iterations, projection method, upwind
+flux, Taylor-Green vortex with exponential forcing, dt = 0.25/nx) on the
+configuration named in ``config.workload`` -- by default C3: k = 2, 1024 x 1024 triangular mesh.
+All state is resident in HBM when the timed region starts.
+
+    python bench.py --gpus N --steps K --warmup W [--nx 1024 --degree 2]
+
+Prints ONE JSON line (rank 0) with the driver's contract plus ``roofline`` (dominant kernel, HIP
+events on the engine's stream) and ``cpu_baseline`` (the numpy/scipy oracle timed on a bounded
+sample of the same workload on this box's host cores, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def ssp2_scales(nsteps, dt, kappa, t0=0.0):
+    """Forcing scalars g(t_n + c_i dt), i = 0..s-1, and g(t_n + dt) for the separable TG forcing."""
+    c = [0.0, 1.0, 0.5]  # hdg_imex.py:949, as written
+    g = lambda t: -kappa * np.exp(-kappa * t)
+    out = np.zeros((nsteps, 4))
+    for n in range(nsteps):
+        tn = t0 + n * dt
+        out[n, :3] = [g(tn + ci * dt) for ci in c]
+        out[n, 3] = g(tn + dt)
+    return out
+
+
+def cpu_baseline(degree, budget_s=20.0):
+    """Time the CPU oracle (scipy sparse direct solves: the converged limit of the reference's
+    assembled-AIJ + LU/ILU solver stack) on the largest mesh whose single step fits the budget."""
+    from oracle import hdg_oracle as orc
+
+    best = None
+    for nx in (8, 16, 32, 64):
+        d = orc.HDGDiscretisation(nx, degree)
+        tg = orc.TaylorGreen(d)
+        dt = 0.25 / nx
+        o = orc.OracleHDGIMEX(d, dt, "imex_ssp2_332")
+        o.set_initial_condition(*tg.initial_condition())
+        o.step(tg.f_rhs, 0.0)  # warm-up step (mirrors --warmup, driver.py:157-162)
+        t0 = time.perf_counter()
+        nsteps = 2
+        for n in range(nsteps):
+            o.step(tg.f_rhs, (n + 1) * dt)
+        el = time.perf_counter() - t0
+        best = dict(value=d.N * nsteps / el / 1e6, unit="million DOF-updates/s", cores=1, kind="port",
+                    sample=f"oracle (numpy/scipy sparse LU) HDG-IMEX SSP2(3,3,2) k={degree} nx={nx}, "
+                           f"1 warm-up + {nsteps} timed steps, {el:.1f} s")
+        if el * 5 > budget_s:  # the next mesh is 4x the unknowns and >4x the factorisation time
+            break
+    return best
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--nx", type=int, default=1024)
+    ap.add_argument("--degree", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tent-precond", type=int, default=1)
+    ap.add_argument("--trace-precond", type=int, default=1)
+    ap.add_argument("--gmres-restart", type=int, default=8)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist_
+
+        torch.cuda.set_device(local_rank)
+        dist_.init_process_group("nccl")
+        dist = dist_
+
+    from incompressibleeulerhdg_amd._lib import Engine
+    from incompressibleeulerhdg_amd.mesh import UnitSquareMesh
+    from incompressibleeulerhdg_amd.model_problems import TaylorGreen
+    from incompressibleeulerhdg_amd.timesteppers import IncompressibleEulerHDGIMEXSSP2_332
+
+    nx, k = args.nx, args.degree
+    dt = 0.25 / nx
+    kappa = 0.5
+    # Multi-GPU: the strip-partitioned engine is not built yet; until it is,
+    # rank 0 alone advances the whole mesh and the other ranks idle -- reported as such.
+    active = rank == 0
+    value = None
+    if active:
+        ts = IncompressibleEulerHDGIMEXSSP2_332(
+            UnitSquareMesh(nx, nx), k, dt, use_projection_method=True, n_richardson=2, device=local_rank,
+            tent_precond=args.tent_precond, trace_precond=args.trace_precond, gmres_restart=args.gmres_restart)
+        eng = ts._engine
+        mp = TaylorGreen(ts._V_Q, ts._V_p, "exponential", kappa)
+        eng.set_state(ts._V_Q.interpolate(mp.Q_stationary), ts._V_p.interpolate(mp.p_stationary))
+        eng.reconstruct_trace()
+        eng.set_forcing_profile(mp.f_rhs().profile)
+        if args.warmup > 0:
+            eng.run_separable(ssp2_scales(args.warmup, dt, kappa))
+        eng.iteration_stats(reset=True)
+    if dist is not None:
+        import torch
+
+        dist.barrier()
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    if active:
+        eng.run_separable(ssp2_scales(args.steps, dt, kappa, t0=args.warmup * dt))  # synchronous on return
+    if dist is not None:
+        dist.barrier()
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+
+        tmax = torch.tensor([elapsed], device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank == 0:
+        sums, cnt = eng.iteration_stats()
+        its = {n: (float(s / c) if c else 0.0) for n, s, c in zip(
+            ("tentative", "pressure", "final_pressure", "pressure_reconstruction"), sums, cnt)}
+        ntot = eng.n_total
+        value = ntot * args.steps / elapsed / 1e6
+        # --- roofline of the dominant kernel (advection apply, K3): algorithmic bytes = 3 velocity
+        # vectors (x, Q*, y), 8 B per entry, duration from HIP events on the
+        # engine's stream
+        NQ = eng.n_cells * 2 * eng.n_u
+        ms_adv = eng.time_kernel(0, 20)
+        ms_tr = eng.time_kernel(1, 50)
+        ms_bdm = eng.time_kernel(2, 20)
+        ms_bs = eng.time_kernel(3, 20)
+        NL = eng.n_edges * eng.n_l
+        NP = eng.n_cells * eng.n_p
+        adv_bytes = 8.0 * 3 * NQ
+        roof = dict(bound="hbm", kernel="k_adv_apply", achieved=adv_bytes / (ms_adv * 1e-3) / 1e9, peak=HBM_PEAK_GBS,
+                    unit="GB/s", frac=adv_bytes / (ms_adv * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=None,
+                    ms_per_launch=ms_adv,
+                    other_kernels={
+                        "k_trace_apply": dict(ms=ms_tr, GBs=8.0 * 2 * NL / (ms_tr * 1e-3) / 1e9),
+                        "k_edge_lift(bdm)": dict(ms=ms_bdm, GBs=8.0 * 2 * NQ / (ms_bdm * 1e-3) / 1e9),
+                        "k_backsub": dict(ms=ms_bs, GBs=8.0 * (NL + 2 * NQ + 2 * NP) / (ms_bs * 1e-3) / 1e9),
+                    })
+        line = {
+            "metric": "million DOF-updates/sec (HDG-IMEX k=2, 1024^2 tri mesh)" if (nx, k) == (1024, 2)
+            else f"million DOF-updates/sec (HDG-IMEX k={k}, {nx}^2 tri mesh)",
+            "value": value, "unit": "million DOF-updates/s", "n_gpus": args.gpus, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"HDG-IMEX SSP2(3,3,2) R=2 projection upwind, k={k}, {nx}x{nx} tri mesh, "
+                                   f"Taylor-Green kappa=0.5, dt=0.25/nx (BASELINE C3)" if (nx, k) == (1024, 2)
+                       else f"HDG-IMEX SSP2(3,3,2) R=2 projection upwind, k={k}, {nx}x{nx} tri mesh",
+                       "n_dof": ntot, "krylov_iterations_avg": its,
+                       "multi_gpu": "single engine on rank 0; other ranks idle (strip partition not built yet)"
+                       if world > 1 else "n/a"},
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(k)
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

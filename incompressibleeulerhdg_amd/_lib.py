@@ -179,7 +179,7 @@ class Engine:
         cfg.equispaced_nodes = 1 if kw.get("node_variant", "gll") == "equispaced" else 0
         cfg.tent_rtol = float(kw.get("tent_rtol", 1e-10))
         cfg.tent_maxit = int(kw.get("tent_maxit", 2000))
-        cfg.gmres_restart = int(kw.get("gmres_restart", 30))
+        cfg.gmres_restart = int(kw.get("gmres_restart", 8))
         cfg.tent_precond = int(kw.get("tent_precond", 1))
         cfg.trace_rtol = float(kw.get("trace_rtol", 1e-12))
         cfg.trace_maxit = int(kw.get("trace_maxit", 10000))

@@ -236,10 +236,10 @@ struct Engine {
   }
 
   void bdm(const double* in, double* out) {
-    HDG_DISPATCH(k_edge_lift<KK><<<cell_grid(), bs(), 0, stream>>>(g, in, out, d_tabN, d_tabLift));
+    HDG_DISPATCH(k_edge_lift<KK, false><<<cell_grid(), bs(), 0, stream>>>(g, dt, in, out));
   }
   void bdm_T(const double* in, double* out) {
-    HDG_DISPATCH(k_edge_lift<KK><<<cell_grid(), bs(), 0, stream>>>(g, in, out, d_tabLiftT, d_tabNt));
+    HDG_DISPATCH(k_edge_lift<KK, true><<<cell_grid(), bs(), 0, stream>>>(g, dt, in, out));
   }
   void adv_apply(const double* x, const double* qstar, double* out, double gamma) {
     const double up = cfg.flux_upwind ? 1.0 : 0.0;

@@ -117,10 +117,9 @@ __device__ __forceinline__ void mv_acc_ld(const double* __restrict__ A, int LD, 
 //   With (In, Out) = (N, Lift) this is the BDM projection Q -> Q* (common.py:91-108);
 //   with (In, Out) = (Lift^T, N^T) it is its transpose (used by the two-level preconditioner).
 // ------------------------------------------------------------------------------------------
-template <int K>
-__global__ __launch_bounds__(128) void k_edge_lift(Geo g, const double* __restrict__ in, double* __restrict__ out,
-                                                    const double* const* __restrict__ tabIn,
-                                                    const double* const* __restrict__ tabOut) {
+template <int K, bool TRANSPOSE>
+__global__ __launch_bounds__(128) void k_edge_lift(Geo g, DevTables T, const double* __restrict__ in,
+                                                    double* __restrict__ out) {
   constexpr int NU = Dim<K>::NU, NE = Dim<K>::NE, N2 = 2 * NU;
   HDG_CELL_PROLOGUE
   double x[N2], y[N2];
@@ -129,19 +128,22 @@ __global__ __launch_bounds__(128) void k_edge_lift(Geo g, const double* __restri
   for (int n = 0; n < N2; n++) y[n] = x[n];
 #pragma unroll
   for (int e = 0; e < 3; e++) {
+    const double* __restrict__ Iown = TRANSPOSE ? T.LiftT[s][e] : T.N[s][e];
+    const double* __restrict__ Inb = TRANSPOSE ? T.LiftT[1 - s][e] : T.N[1 - s][e];
+    const double* __restrict__ Out = TRANSPOSE ? T.Nt[s][e] : T.Lift[s][e];
     double d[NE];
 #pragma unroll
     for (int a = 0; a < NE; a++) d[a] = 0.0;
-    mv_acc<NE, N2>(tabIn[s * 3 + e], x, d, -1.0);
+    mv_acc<NE, N2>(Iown, x, d, -1.0);
     long cn;
     if (nbr(s, e, i, j, g, cn)) {
       double xn[N2];
       load_cell<N2>(in, g.Nc, cn, xn);
-      mv_acc<NE, N2>(tabIn[(1 - s) * 3 + e], xn, d, 1.0);
+      mv_acc<NE, N2>(Inb, xn, d, 1.0);
 #pragma unroll
       for (int a = 0; a < NE; a++) d[a] *= 0.5;
     }
-    mv_acc<N2, NE>(tabOut[s * 3 + e], d, y, 1.0);
+    mv_acc<N2, NE>(Out, d, y, 1.0);
   }
   store_cell<N2>(out, g.Nc, c, y);
 }

@@ -1,0 +1,151 @@
+"""CPU tests of the host side: C-ABI library loads and exports every declared symbol, class surface
+matches the reference, host utilities behave like the reference's."""
+import ctypes
+import inspect
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from incompressibleeulerhdg_amd import _lib
+
+    _lib.build_library()
+    lib = _lib.load_library()
+    header = open(os.path.join(ROOT, "include", "hdg_mi355x.h")).read()
+    declared = set(re.findall(r"\b(hdg_[a-z0-9_]+)\s*\(", header))
+    declared.discard("hdg_handle")
+    assert len(declared) >= 30
+    for name in declared:
+        assert hasattr(lib, name), name
+    # the ctypes signature table covers the same set
+    assert declared == set(_lib.SIGNATURES) | {"hdg_last_error"}
+
+
+def test_config_struct_layout_matches_header():
+    from incompressibleeulerhdg_amd import _lib
+
+    header = open(os.path.join(ROOT, "include", "hdg_mi355x.h")).read()
+    body = header[header.index("typedef struct hdg_config {"):header.index("} hdg_config;")]
+    fields = re.findall(r"\b(?:int|double)\s+([^;]+);", body)
+    names = []
+    for f in fields:
+        for part in f.split(","):
+            names.append(re.match(r"\s*([a-z_]+)", part).group(1))
+    assert names == [n for n, _ in _lib.hdg_config._fields_]
+
+
+def test_no_gpu_gives_an_error_code_not_a_crash():
+    """Without a GPU hdg_create must fail with HDG_ERR_HIP (no CPU fallback, no abort)."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from incompressibleeulerhdg_amd._lib import Engine, HDGError
+
+    with pytest.raises(HDGError) as ei:
+        Engine(nx=4, degree=1, dt=0.1, nstages=2, a_expl=[[0, 0], [1, 0]], a_impl=[[0, 0], [0, 1]], b_expl=[1, 0],
+               b_impl=[0, 1], c_expl=[0, 1])
+    assert ei.value.code == -2
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "incompressibleeulerhdg_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), os.path.join(dirpath, f)
+
+
+def test_class_surface_matches_reference():
+    """Constructor / method names and argument order of hdg_imex.py:29-39,258,275,505 and
+    hdg_implicit.py:17-25,52."""
+    from incompressibleeulerhdg_amd import timesteppers as ts
+
+    base = ts.IncompressibleEulerHDGIMEX
+    sig = list(inspect.signature(base.__init__).parameters)
+    assert sig[:9] == ["self", "mesh", "degree", "dt", "flux", "use_projection_method", "n_richardson", "label", "callbacks"]
+    for name in ("IncompressibleEulerHDGIMEXImplicit", "IncompressibleEulerHDGIMEXARS2_232",
+                 "IncompressibleEulerHDGIMEXARS3_443", "IncompressibleEulerHDGIMEXSSP2_332",
+                 "IncompressibleEulerHDGIMEXSSP3_433"):
+        cls = getattr(ts, name)
+        assert issubclass(cls, base)
+        assert list(inspect.signature(cls.__init__).parameters)[:8] == [
+            "self", "mesh", "degree", "dt", "flux", "use_projection_method", "n_richardson", "callbacks"]
+    assert list(inspect.signature(base.solve).parameters)[:7] == [
+        "self", "Q_initial", "p_initial", "q_initial", "f_rhs", "T_final", "warmup"]
+    for m in ("pressure_solve", "tentative_velocity_solve", "project_bdm", "get_timesteps", "_shift_pressure",
+              "_reconstruct_trace"):
+        assert hasattr(base, m)
+    imp = ts.IncompressibleEulerHDGImplicit
+    assert list(inspect.signature(imp.__init__).parameters)[:7] == [
+        "self", "mesh", "degree", "dt", "flux", "use_projection_method", "callbacks"]
+    assert "n_richardson" in inspect.signature(imp.__init__).parameters  # driver.py:220-228 (SURVEY C-1)
+
+
+def test_tableau_properties_equal_oracle_literals():
+    from incompressibleeulerhdg_amd import timesteppers as ts
+    from oracle.hdg_oracle import TABLEAUX
+
+    pairs = {"imex_implicit": ts.IncompressibleEulerHDGIMEXImplicit, "imex_ars2_232": ts.IncompressibleEulerHDGIMEXARS2_232,
+             "imex_ars3_443": ts.IncompressibleEulerHDGIMEXARS3_443, "imex_ssp2_332": ts.IncompressibleEulerHDGIMEXSSP2_332,
+             "imex_ssp3_433": ts.IncompressibleEulerHDGIMEXSSP3_433}
+    for key, cls in pairs.items():
+        t = TABLEAUX[key]
+        for attr, name in (("_a_expl", "a_expl"), ("_a_impl", "a_impl"), ("_b_expl", "b_expl"), ("_b_impl", "b_impl"),
+                           ("_c_expl", "c_expl")):
+            got = getattr(cls, attr).fget(None)
+            assert np.array_equal(got, np.asarray(t[name], dtype=float)), (key, attr)
+        assert cls.nstages.fget(None) == len(t["c_expl"])
+        assert cls.__name__.startswith("IncompressibleEulerHDGIMEX")
+
+
+def test_performance_log_and_averager():
+    from incompressibleeulerhdg_amd.auxilliary.logging import PerformanceLog, log_summary
+    from incompressibleeulerhdg_amd.auxilliary.utils import Averager
+
+    PerformanceLog.reset()
+    with PerformanceLog("timestep"):
+        pass
+
+    @PerformanceLog("pressure_solve")
+    def f():
+        return 3
+
+    assert f() == 3 and f() == 3
+    assert len(PerformanceLog.data["timestep"]) == 1 and len(PerformanceLog.data["pressure_solve"]) == 2
+    log_summary()
+    a = Averager()
+    for x in (1, 2, 6):
+        a.update(x)
+    assert a.value == 3 and a.n_samples == 3
+
+
+def test_get_timesteps_and_model_problem():
+    from incompressibleeulerhdg_amd.mesh import FunctionSpace, UnitSquareMesh
+    from incompressibleeulerhdg_amd.model_problems import TaylorGreen
+    from incompressibleeulerhdg_amd.timesteppers.common import IncompressibleEuler
+
+    class T(IncompressibleEuler):
+        def solve(self, *a, **k):
+            pass
+
+    t = T(UnitSquareMesh(4, 4), 1, 0.04)
+    assert t.get_timesteps(1.0, False) == 25 and t.get_timesteps(1.0, True) == 1
+    with pytest.raises(AssertionError):
+        t.get_timesteps(0.05, False)
+    xy = np.array([[0.0, 0.0], [0.5, 0.5], [1.0, 0.25]])
+    VQ = FunctionSpace(None, "DG", 2, xy, 2)
+    Vp = FunctionSpace(None, "DG", 1, xy, 1)
+    mp = TaylorGreen(VQ, Vp, "exponential", 0.5)
+    f = mp.f_rhs()
+    assert np.allclose(f(0.3), -0.5 * np.exp(-0.15) * mp._Qs)
+    assert np.allclose(mp._Qs[1], [0.0, 0.0]) and abs(mp._ps[1]) < 1e-15
+    Q, p = mp.solution(0.2)
+    assert np.allclose(Q.dat.data, np.exp(-0.1) * mp._Qs)
+    assert TaylorGreen(VQ, Vp, "constant", 0.0).f_rhs().scale(1.0) == 0.0
