@@ -79,6 +79,7 @@ struct Engine {
   const double** d_ones_ptr = nullptr;
   std::vector<double*> gm_V;  // GMRES basis (restart+1)
   const double** d_ptrs = nullptr;
+  const double** d_gmV = nullptr;  // device array of the GMRES basis pointers
   double* d_part = nullptr;
   double* d_res = nullptr;
   double* d_coef = nullptr;
@@ -125,8 +126,8 @@ struct Engine {
     return t;
   }
 
-  dim3 cell_grid() const { return dim3((g.nx + bs() - 1) / bs(), g.ny, 2); }
-  dim3 corner_grid() const { return dim3((g.nx + 1 + bs() - 1) / bs(), g.ny + 1, 1); }
+  dim3 cell_grid() const { return dim3(8 * g.rows_xcd * 2 * g.nbx, 1, 1); }
+  dim3 corner_grid() const { return dim3(8 * g.rows_xcdc * g.nbxc, 1, 1); }
   int bs() const { return g.nx <= 64 ? 64 : 128; }
   int vec_blocks(long n) const { return (int)std::min<long>((n + 255) / 256, 2048); }
 
@@ -147,6 +148,10 @@ struct Engine {
     g.G = (long)(c.ny + 1) * g.P;
     g.Nc = 2L * c.nx * c.ny;
     g.h = 1.0 / c.nx;
+    g.nbx = (g.nx + bs() - 1) / bs();
+    g.nbxc = (g.nx + 1 + bs() - 1) / bs();
+    g.rows_xcd = (g.ny + 7) / 8;
+    g.rows_xcdc = (g.ny + 1 + 7) / 8;
     NQ = 2L * NU * g.Nc; NPv = (long)NP * g.Nc; NLv = 3L * NL * g.G;
     tab = new Tables(K, g.h, c.tau, c.alpha_penalty, c.equispaced_nodes);
     build_dev_tables();
@@ -211,7 +216,14 @@ struct Engine {
     k_fill<<<vec_blocks(g.Nc), 256, 0, stream>>>(g.Nc, ones_c, 1.0);
     d_ones_ptr = upload_ptrs({ones_c});
     int m = std::max(1, cfg.gmres_restart);
+    m = std::min(m, MAXV - 1);
     for (int i = 0; i <= m; i++) gm_V.push_back(dalloc(NQ));
+    {
+      std::vector<const double*> pv(gm_V.begin(), gm_V.end());
+      pv.push_back(nullptr);
+      pv.push_back(nullptr);
+      d_gmV = upload_ptrs(pv);
+    }
     void* p = nullptr;
     HIPCHECK(hipMalloc(&p, sizeof(double*) * (std::max(m, MAXV) + 2)));
     allocs.push_back(p);
@@ -236,10 +248,14 @@ struct Engine {
   }
 
   void bdm(const double* in, double* out) {
-    HDG_DISPATCH(k_edge_lift<KK, false><<<cell_grid(), bs(), 0, stream>>>(g, dt, in, out));
+    HDG_DISPATCH(k_edge_lift<KK, false, false><<<cell_grid(), bs(), 0, stream>>>(g, dt, in, out, nullptr, nullptr, nullptr));
+  }
+  // out = Pi(in) + Dinv r   (second half of the two-level preconditioner, block-Jacobi fused in)
+  void bdm_plus_bj(const double* in, double* out, const double* r, const double* D0, const double* D1) {
+    HDG_DISPATCH(k_edge_lift<KK, false, true><<<cell_grid(), bs(), 0, stream>>>(g, dt, in, out, r, D0, D1));
   }
   void bdm_T(const double* in, double* out) {
-    HDG_DISPATCH(k_edge_lift<KK, true><<<cell_grid(), bs(), 0, stream>>>(g, dt, in, out));
+    HDG_DISPATCH(k_edge_lift<KK, true, false><<<cell_grid(), bs(), 0, stream>>>(g, dt, in, out, nullptr, nullptr, nullptr));
   }
   void adv_apply(const double* x, const double* qstar, double* out, double gamma) {
     const double up = cfg.flux_upwind ? 1.0 : 0.0;
@@ -420,30 +436,30 @@ struct Engine {
       blockdiag(dinv0[didx], dinv1[didx], r, nullptr, 0.0, z);
     } else {
       bdm_T(r, wQ3);
-      bdm(wQ3, wQ4);
-      blockdiag(dinv0[didx], dinv1[didx], r, wQ4, 1.0, z);
+      bdm_plus_bj(wQ3, z, r, dinv0[didx], dinv1[didx]);
     }
   }
   // solve (I - gamma F(Q*)) x = b with left-preconditioned GMRES(m); x holds the initial guess.
   // Convergence: ||M r|| <= rtol * ||M r0||  (PETSc default for the SNES-ksponly linear solve the
   // reference performs: relative to the residual at the warm start)
   int gmres(const double* qstar, double gamma, int didx, const double* b, double* x) {
-    const int m = std::max(1, cfg.gmres_restart);
+    const int m = std::min(std::max(1, cfg.gmres_restart), MAXV - 1);
     const double rtol = cfg.tent_rtol;
     int its = 0;
     double beta0 = -1.0;
     std::vector<double> H((size_t)(m + 1) * m, 0.0), cs(m), sn(m), gv(m + 1);
     double* w = wQ1;
     double* t = wQ2;
+    const int nvb = vec_blocks(NQ);
     while (true) {
       adv_apply(x, qstar, t, gamma);       // t = A x
       axpby(NQ, 1.0, b, -1.0, t);          // t = b - A x
-      tent_precond(didx, t, gm_V[0]);
-      double beta = std::sqrt(dot(NQ, gm_V[0], gm_V[0]));
+      tent_precond(didx, t, w);
+      double beta = std::sqrt(dot(NQ, w, w));
       if (beta0 < 0) beta0 = beta;
       if (!(beta == beta)) throw NotConverged{"GMRES: NaN residual"};
       if (beta <= rtol * beta0 || beta == 0.0) return its;
-      axpby(NQ, 0.0, gm_V[0], 1.0 / beta, gm_V[0]);  // V0 *= 1/beta   (y = a*x + b*y with a=0)
+      k_gs_update<MAXV><<<nvb, 256, 0, stream>>>(NQ, w, d_gmV, Coefs(), 0, 1.0 / beta, gm_V[0]);
       std::fill(gv.begin(), gv.end(), 0.0);
       gv[0] = beta;
       int j = 0;
@@ -451,14 +467,31 @@ struct Engine {
       for (; j < m; j++) {
         adv_apply(gm_V[j], qstar, t, gamma);
         tent_precond(didx, t, w);
-        std::vector<const double*> V(gm_V.begin(), gm_V.begin() + j + 1);
-        std::vector<double> h(j + 1);
-        multidot(NQ, w, V, h.data());
-        multiaxpy(NQ, w, V, h, -1.0);
-        double hn = std::sqrt(dot(NQ, w, w));
+        // one pass: h_l = (w, V_l), l <= j, and (w, w); then ||w - V h||^2 = (w,w) - sum h_l^2
+        std::vector<double> h(j + 2);
+        {
+          // pointer list = V_0..V_j followed by w: gather through a small staging array
+          std::vector<const double*> ptrs(gm_V.begin(), gm_V.begin() + j + 1);
+          ptrs.push_back(w);
+          multidot(NQ, w, ptrs, h.data());
+        }
+        double ww = h[j + 1], s2 = 0.0;
+        for (int l = 0; l <= j; l++) s2 += h[l] * h[l];
+        double hn2 = ww - s2;
+        Coefs hc;
+        for (int l = 0; l <= j; l++) hc.c[l] = h[l];
+        double hn;
+        if (hn2 > 1e-6 * ww) {
+          hn = std::sqrt(hn2);
+          k_gs_update<MAXV><<<nvb, 256, 0, stream>>>(NQ, w, d_gmV, hc, j + 1, 1.0 / hn, gm_V[j + 1]);
+        } else {
+          // severe cancellation: orthogonalise explicitly and measure the norm (safe path)
+          k_gs_update<MAXV><<<nvb, 256, 0, stream>>>(NQ, w, d_gmV, hc, j + 1, 1.0, gm_V[j + 1]);
+          hn = std::sqrt(dot(NQ, gm_V[j + 1], gm_V[j + 1]));
+          if (hn > 0) axpby(NQ, 0.0, w, 1.0 / hn, gm_V[j + 1]);
+        }
         for (int l = 0; l <= j; l++) H[(size_t)l * m + j] = h[l];
         H[(size_t)(j + 1) * m + j] = hn;
-        // apply previous Givens rotations
         for (int l = 0; l < j; l++) {
           double a1 = H[(size_t)l * m + j], a2 = H[(size_t)(l + 1) * m + j];
           H[(size_t)l * m + j] = cs[l] * a1 + sn[l] * a2;
@@ -474,19 +507,18 @@ struct Engine {
         gv[j] = cs[j] * gv[j];
         its++;
         double res = std::fabs(gv[j + 1]);
-        if (hn > 0) { copy(gm_V[j + 1], w, NQ); axpby(NQ, 0.0, w, 1.0 / hn, gm_V[j + 1]); }
         if (res <= rtol * beta0 || hn == 0.0) { j++; done = true; break; }
         if (its >= cfg.tent_maxit) { j++; done = false; break; }
       }
-      // solve the j x j triangular system and update x
+      Coefs yc;
       std::vector<double> y(j, 0.0);
       for (int l = j - 1; l >= 0; l--) {
         double acc = gv[l];
         for (int q = l + 1; q < j; q++) acc -= H[(size_t)l * m + q] * y[q];
         y[l] = acc / H[(size_t)l * m + l];
       }
-      std::vector<const double*> V(gm_V.begin(), gm_V.begin() + j);
-      multiaxpy(NQ, x, V, y, 1.0);
+      for (int l = 0; l < j; l++) yc.c[l] = y[l];
+      k_basis_axpy<MAXV><<<nvb, 256, 0, stream>>>(NQ, x, d_gmV, yc, j);
       if (done) return its;
       if (its >= cfg.tent_maxit) throw NotConverged{"tentative-velocity GMRES reached max iterations"};
     }

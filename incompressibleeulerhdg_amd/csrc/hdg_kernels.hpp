@@ -22,6 +22,14 @@ struct Geo {
   long G;   // (ny+1)*P : one trace plane
   long Nc;  // 2*nx*ny
   double h;
+  // XCD-aware block mapping (1-D grids): workgroups are dealt round-robin over the 8 XCDs, so
+  // blockIdx % 8 labels the XCD.  Each XCD owns a contiguous band of mesh rows and walks it row by
+  // row with both element shapes of a row adjacent in its sequence: the neighbour gathers (other
+  // shape of the same square, rows j-1 / j+1) then hit that XCD's L2 instead of HBM.
+  int nbx;       // blocks per row of cells
+  int nbxc;      // blocks per row of corners
+  int rows_xcd;  // cell rows per XCD band      = ceil(ny / 8)
+  int rows_xcdc; // corner rows per XCD band    = ceil((ny+1) / 8)
 };
 
 template <int K>
@@ -46,11 +54,13 @@ struct DevTables {
   int nqc, nqe;
 };
 
-#define HDG_CELL_PROLOGUE                                   \
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;      \
-  const int j = blockIdx.y;                                 \
-  const int s = blockIdx.z;                                 \
-  if (i >= g.nx) return;                                    \
+#define HDG_CELL_PROLOGUE                                          \
+  const int xcd_ = blockIdx.x & 7, q_ = blockIdx.x >> 3;           \
+  const int jj_ = q_ / (2 * g.nbx), rem_ = q_ - jj_ * 2 * g.nbx;   \
+  const int s = rem_ / g.nbx;                                      \
+  const int i = (rem_ - s * g.nbx) * blockDim.x + threadIdx.x;     \
+  const int j = xcd_ * g.rows_xcd + jj_;                           \
+  if (jj_ >= g.rows_xcd || j >= g.ny || i >= g.nx) return;         \
   const long c = ((long)s * g.ny + j) * g.nx + i;
 
 __device__ __forceinline__ bool nbr(int s, int e, int i, int j, const Geo& g, long& cn) {
@@ -117,15 +127,22 @@ __device__ __forceinline__ void mv_acc_ld(const double* __restrict__ A, int LD, 
 //   With (In, Out) = (N, Lift) this is the BDM projection Q -> Q* (common.py:91-108);
 //   with (In, Out) = (Lift^T, N^T) it is its transpose (used by the two-level preconditioner).
 // ------------------------------------------------------------------------------------------
-template <int K, bool TRANSPOSE>
+//   Optional fused epilogue (two-level preconditioner): out += Dinv_s * r_K  (element block-Jacobi).
+template <int K, bool TRANSPOSE, bool ADD_BJ>
 __global__ __launch_bounds__(128) void k_edge_lift(Geo g, DevTables T, const double* __restrict__ in,
-                                                    double* __restrict__ out) {
+                                                    double* __restrict__ out, const double* __restrict__ r,
+                                                    const double* __restrict__ Dinv0, const double* __restrict__ Dinv1) {
   constexpr int NU = Dim<K>::NU, NE = Dim<K>::NE, N2 = 2 * NU;
   HDG_CELL_PROLOGUE
   double x[N2], y[N2];
   load_cell<N2>(in, g.Nc, c, x);
 #pragma unroll
   for (int n = 0; n < N2; n++) y[n] = x[n];
+  if (ADD_BJ) {
+    double rr[N2];
+    load_cell<N2>(r, g.Nc, c, rr);
+    mv_acc<N2, N2>(s == 0 ? Dinv0 : Dinv1, rr, y, 1.0);
+  }
 #pragma unroll
   for (int e = 0; e < 3; e++) {
     const double* __restrict__ Iown = TRANSPOSE ? T.LiftT[s][e] : T.N[s][e];
@@ -357,11 +374,13 @@ __global__ __launch_bounds__(128) void k_weak_div(Geo g, DevTables T, const doub
 // ------------------------------------------------------------------------------------------
 // corner-thread helpers for the trace space
 // ------------------------------------------------------------------------------------------
-#define HDG_CORNER_PROLOGUE                               \
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;    \
-  const int j = blockIdx.y;                               \
-  if (i > g.nx) return;                                   \
-  const long o = (long)j * g.P + i;                       \
+#define HDG_CORNER_PROLOGUE                                        \
+  const int xcd_ = blockIdx.x & 7, q_ = blockIdx.x >> 3;           \
+  const int jj_ = q_ / g.nbxc;                                     \
+  const int i = (q_ - jj_ * g.nbxc) * blockDim.x + threadIdx.x;    \
+  const int j = xcd_ * g.rows_xcdc + jj_;                          \
+  if (jj_ >= g.rows_xcdc || j > g.ny || i > g.nx) return;          \
+  const long o = (long)j * g.P + i;                                \
   const bool in_x = i < g.nx, in_y = j < g.ny;
 
 template <int NL>
@@ -859,6 +878,36 @@ __global__ void k_multiaxpy(long N, double* __restrict__ w, const double* const*
   }
 }
 
+// coefficients passed by value (kernel arguments): no host->device copy, no extra sync
+struct Coefs {
+  double c[32];
+};
+// out = scale * (w - sum_k h[k] V[k])     (classical Gram-Schmidt update fused with the normalisation)
+template <int MAXV>
+__global__ void k_gs_update(long N, const double* __restrict__ w, const double* const* __restrict__ V, Coefs h, int nv,
+                            double scale, double* __restrict__ out) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < N; idx += stride) {
+    double acc = w[idx];
+#pragma unroll
+    for (int k = 0; k < MAXV; k++)
+      if (k < nv) acc = fma(-h.c[k], V[k][idx], acc);
+    out[idx] = scale * acc;
+  }
+}
+// x += sum_k y[k] V[k]
+template <int MAXV>
+__global__ void k_basis_axpy(long N, double* __restrict__ x, const double* const* __restrict__ V, Coefs y, int nv) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < N; idx += stride) {
+    double acc = x[idx];
+#pragma unroll
+    for (int k = 0; k < MAXV; k++)
+      if (k < nv) acc = fma(y.c[k], V[k][idx], acc);
+    x[idx] = acc;
+  }
+}
+
 // pressure / trace mean shift (hdg_imex.py:471-478): p -= pbar, lambda -= pbar (modal mode 0 only)
 __global__ void k_shift_p(long Nc, double* __restrict__ p, const double* __restrict__ sum0, double factor, double c0) {
   // pbar = factor * sum0[0];  p_{K,0} -= pbar * c0
@@ -868,12 +917,8 @@ __global__ void k_shift_p(long Nc, double* __restrict__ p, const double* __restr
 }
 __global__ void k_shift_l(Geo g, int NL, double* __restrict__ l, const double* __restrict__ sum0, double factor,
                           double sH, double sV, double sD) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int j = blockIdx.y;
-  if (i > g.nx) return;
+  HDG_CORNER_PROLOGUE
   const double pbar = factor * sum0[0];
-  const long o = (long)j * g.P + i;
-  const bool in_x = i < g.nx, in_y = j < g.ny;
   if (in_x) l[((long)0 * NL) * g.G + o] -= pbar * sH;
   if (in_y) l[((long)1 * NL) * g.G + o] -= pbar * sV;
   if (in_x && in_y) l[((long)2 * NL) * g.G + o] -= pbar * sD;
