@@ -149,8 +149,16 @@ def main():
         NL = eng.n_edges * eng.n_l
         NP = eng.n_cells * eng.n_p
         adv_bytes = 8.0 * 3 * NQ
+        traffic = None
+        try:  # HBM bytes per launch from the committed PMC passes (same workload only)
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            if tj["workload"] == {"nx": nx, "degree": k}:
+                traffic = tj["kernels"]["k_adv_apply"]["hbm_bytes"]
+        except Exception:
+            traffic = None
         roof = dict(bound="hbm", kernel="k_adv_apply", achieved=adv_bytes / (ms_adv * 1e-3) / 1e9, peak=HBM_PEAK_GBS,
-                    unit="GB/s", frac=adv_bytes / (ms_adv * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=None,
+                    unit="GB/s", frac=adv_bytes / (ms_adv * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=traffic,
+                    algorithmic_bytes=adv_bytes,
                     ms_per_launch=ms_adv,
                     other_kernels={
                         "k_trace_apply": dict(ms=ms_tr, GBs=8.0 * 2 * NL / (ms_tr * 1e-3) / 1e9),

@@ -141,3 +141,20 @@ def test_hdg_implicit_projection(hip_lib, k, nx):
     tg = orc.TaylorGreen(d)
     oQ, op = orc.OracleHDGImplicit(d, dt).solve(*tg.initial_condition(), tg.f_rhs, 3 * dt)
     assert _relerr(Q.dat.data, oQ) < TOL and _relerr(p.dat.data, op) < TOL
+
+
+def test_driver_prints_reference_quantities(hip_lib, capsys):
+    """driver.py:284-306,379-380: same parameter echo and the two error norms."""
+    from incompressibleeulerhdg_amd import driver
+
+    rc = driver.main(["--nx", "8", "--degree", "1", "--dt", "0.05", "--tfinal", "0.2", "--use_projection_method"])
+    out = capsys.readouterr().out
+    assert rc == 0
+    for needle in ("mesh size = 8 x 8", "timestepping method = HDG IMEX SSP2(3,3,2)", "number of Richardson iterations = 2",
+                   "tentative velocity its", "pressure reconstruction its", "velocity error = ", "pressure error = ", "timestep"):
+        assert needle in out
+    err = float(out.split("velocity error = ")[1].split()[0])
+    assert 0 < err < 5e-3
+    rc = driver.main(["--nx", "8", "--test_pressure_solver", "--use_projection_method"])
+    out = capsys.readouterr().out
+    assert rc == 0 and "number of iterations" in out
