@@ -52,7 +52,7 @@ typedef struct hdg_config {
   int degree;            /* k = pressure degree (common.py:27), 1..4 */
   double dt;
   int flux_upwind;       /* 1 "upwind", 0 "centered" (hdg_imex.py:325) */
-  int use_projection;    /* hdg_imex.py:53 (0 -> HDG_ERR_UNSUPPORTED in this round) */
+  int use_projection;    /* hdg_imex.py:53; 0 selects the unsplit (monolithic) stage solve */
   int n_richardson;      /* hdg_imex.py:60 */
   double tau;            /* hdg_imex.py:58 */
   double alpha_penalty;  /* hdg_imex.py:56 */
@@ -70,6 +70,10 @@ typedef struct hdg_config {
   double trace_rtol;     /* 1e-12 (hdg_imex.py:137) */
   int trace_maxit;
   int trace_precond;     /* 0 edge block-Jacobi, 1 GTMG-like two-level (P1 coarse space + geometric MG) */
+  double unsplit_rtol;       /* outer FGMRES of the unsplit (monolithic) solves, relative to the initial residual */
+  double unsplit_inner_rtol; /* inexact inner tentative / pressure solves of its preconditioner */
+  int unsplit_restart;
+  int unsplit_maxit;
   int device;            /* HIP device ordinal */
 } hdg_config;
 
@@ -111,6 +115,9 @@ int hdg_project_bdm_nodal(hdg_handle* h, const double* Qin, double* Qout);
 int hdg_begin_step(hdg_handle* h);
 /* tentative_velocity_solve("stage_i") (hdg_imex.py:274-281); returns Krylov iterations */
 int hdg_tentative_solve(hdg_handle* h, int stage, int* its);
+/* the "unsplit_solve" branch (hdg_imex.py:600-620): monolithic (u, phi, lambda) solve of stage i into
+ * _stage_state[i]; returns outer Krylov iterations */
+int hdg_unsplit_solve(hdg_handle* h, int stage, int* its);
 /* pressure_solve(key) (hdg_imex.py:257-272); returns condensed-Krylov iterations */
 int hdg_pressure_solve(hdg_handle* h, int key, int* its);
 /* _shift_pressure(state) (hdg_imex.py:471-478) */
@@ -124,8 +131,8 @@ int hdg_step(hdg_handle* h);
 /* nsteps fused steps with separable forcing: scales[n*(nstages+1) + slot] */
 int hdg_run_separable(hdg_handle* h, int nsteps, const double* scales);
 
-/* one step of IncompressibleEulerHDGImplicit.solve with the projection method
- * (hdg_implicit.py:92-190); forcing slot 0 holds f(t_k) */
+/* one step of IncompressibleEulerHDGImplicit.solve (hdg_implicit.py:92-190), projection method or
+ * monolithic according to cfg.use_projection; forcing slot 0 holds f(t_k) */
 int hdg_implicit_step(hdg_handle* h, int* its_tentative, int* its_pressure);
 
 /* iteration statistics accumulated since the last reset (hdg_imex.py:90-93,648-658):

@@ -56,6 +56,10 @@ class hdg_config(C.Structure):
         ("trace_rtol", C.c_double),
         ("trace_maxit", C.c_int),
         ("trace_precond", C.c_int),
+        ("unsplit_rtol", C.c_double),
+        ("unsplit_inner_rtol", C.c_double),
+        ("unsplit_restart", C.c_int),
+        ("unsplit_maxit", C.c_int),
         ("device", C.c_int),
     ]
 
@@ -97,6 +101,7 @@ SIGNATURES = {
     "hdg_begin_step": [_h],
     "hdg_tentative_solve": [_h, C.c_int, _ip],
     "hdg_pressure_solve": [_h, C.c_int, _ip],
+    "hdg_unsplit_solve": [_h, C.c_int, _ip],
     "hdg_shift_pressure": [_h, C.c_int],
     "hdg_stage_update": [_h, C.c_int],
     "hdg_finish_step": [_h],
@@ -184,6 +189,10 @@ class Engine:
         cfg.trace_rtol = float(kw.get("trace_rtol", 1e-12))
         cfg.trace_maxit = int(kw.get("trace_maxit", 10000))
         cfg.trace_precond = int(kw.get("trace_precond", 1))
+        cfg.unsplit_rtol = float(kw.get("unsplit_rtol", 1e-10))
+        cfg.unsplit_inner_rtol = float(kw.get("unsplit_inner_rtol", 1e-3))
+        cfg.unsplit_restart = int(kw.get("unsplit_restart", 30))
+        cfg.unsplit_maxit = int(kw.get("unsplit_maxit", 600))
         cfg.device = int(kw.get("device", 0))
         self.cfg = cfg
         self.h = _h()
@@ -265,6 +274,11 @@ class Engine:
     def tentative_solve(self, stage):
         its = C.c_int()
         self._ck(self.lib.hdg_tentative_solve(self.h, stage, C.byref(its)))
+        return its.value
+
+    def unsplit_solve(self, stage):
+        its = C.c_int()
+        self._ck(self.lib.hdg_unsplit_solve(self.h, stage, C.byref(its)))
         return its.value
 
     def pressure_solve(self, key):

@@ -89,6 +89,13 @@ struct Engine {
   std::vector<double> dinv_gamma;
   // trace Chebyshev bounds
   double cheb_lmin = 0, cheb_lmax = 0;
+  // operator sets of the hybridised mixed Poisson problem, one per stabilisation parameter tau':
+  // set 0 (tau) serves the projection method; the unsplit solves use tau/gamma (see mono_precond)
+  struct PSet { DevTables dt; double lmin, lmax, tau; };
+  std::vector<PSet> psets;
+  int cur_pset = 0;
+  const DevTables& pdt() const { return psets[cur_pset].dt; }
+  void use_pset(int i) { cur_pset = i; cheb_lmin = psets[i].lmin; cheb_lmax = psets[i].lmax; }
   // multigrid levels (vertex grids)
   std::vector<int> mg_n;
   std::vector<double*> mg_x, mg_b, mg_r;
@@ -273,20 +280,26 @@ struct Engine {
     else { HDG_DISPATCH(k_weak_div<KK, false><<<cell_grid(), bs(), 0, stream>>>(g, dt, q, sc, out)); }
   }
   void trace_apply(const double* lam, const double* base, double cb, double ct, double* out) {
-    HDG_DISPATCH(k_trace_apply<KK><<<corner_grid(), bs(), 0, stream>>>(g, dt, lam, base, cb, ct, out));
+    HDG_DISPATCH(k_trace_apply<KK><<<corner_grid(), bs(), 0, stream>>>(g, pdt(), lam, base, cb, ct, out));
   }
   void trace_cheb(const double* r, double* d, double* x, double c1, double c2) {
-    HDG_DISPATCH(k_trace_cheb<KK><<<corner_grid(), bs(), 0, stream>>>(g, dt, r, d, x, c1, c2));
+    HDG_DISPATCH(k_trace_cheb<KK><<<corner_grid(), bs(), 0, stream>>>(g, pdt(), r, d, x, c1, c2));
   }
   void condense(const double* rw, const double* rp, const double* rl, double* out) {
-    if (rw && !rp) { HDG_DISPATCH(k_condense<KK, true, false><<<corner_grid(), bs(), 0, stream>>>(g, dt, rw, rp, rl, out)); }
-    else if (!rw && rp) { HDG_DISPATCH(k_condense<KK, false, true><<<corner_grid(), bs(), 0, stream>>>(g, dt, rw, rp, rl, out)); }
-    else { HDG_DISPATCH(k_condense<KK, true, true><<<corner_grid(), bs(), 0, stream>>>(g, dt, rw, rp, rl, out)); }
+    if (rw && !rp) { HDG_DISPATCH(k_condense<KK, true, false><<<corner_grid(), bs(), 0, stream>>>(g, pdt(), rw, rp, rl, out)); }
+    else if (!rw && rp) { HDG_DISPATCH(k_condense<KK, false, true><<<corner_grid(), bs(), 0, stream>>>(g, pdt(), rw, rp, rl, out)); }
+    else { HDG_DISPATCH(k_condense<KK, true, true><<<corner_grid(), bs(), 0, stream>>>(g, pdt(), rw, rp, rl, out)); }
   }
   void backsub(const double* rw, const double* rp, const double* lam, double* u, double* phi) {
-    if (rw && !rp) { HDG_DISPATCH(k_backsub<KK, true, false><<<cell_grid(), bs(), 0, stream>>>(g, dt, rw, rp, lam, u, phi)); }
-    else if (!rw && rp) { HDG_DISPATCH(k_backsub<KK, false, true><<<cell_grid(), bs(), 0, stream>>>(g, dt, rw, rp, lam, u, phi)); }
-    else { HDG_DISPATCH(k_backsub<KK, true, true><<<cell_grid(), bs(), 0, stream>>>(g, dt, rw, rp, lam, u, phi)); }
+    if (rw && !rp) { HDG_DISPATCH(k_backsub<KK, true, false><<<cell_grid(), bs(), 0, stream>>>(g, pdt(), rw, rp, lam, u, phi)); }
+    else if (!rw && rp) { HDG_DISPATCH(k_backsub<KK, false, true><<<cell_grid(), bs(), 0, stream>>>(g, pdt(), rw, rp, lam, u, phi)); }
+    else { HDG_DISPATCH(k_backsub<KK, true, true><<<cell_grid(), bs(), 0, stream>>>(g, pdt(), rw, rp, lam, u, phi)); }
+  }
+  void gamma_psi(const double* u, const double* phi, const double* lam, double* out) {
+    HDG_DISPATCH(k_gamma_psi<KK><<<cell_grid(), bs(), 0, stream>>>(g, dt, u, phi, lam, out));
+  }
+  void gamma_mu(const double* u, const double* phi, const double* lam, double* out) {
+    HDG_DISPATCH(k_gamma_mu<KK><<<corner_grid(), bs(), 0, stream>>>(g, dt, u, phi, lam, out));
   }
   void trace_recon(const double* Q, const double* p, double* out) {
     HDG_DISPATCH(k_trace_recon<KK><<<corner_grid(), bs(), 0, stream>>>(g, dt, Q, p, out));
@@ -442,9 +455,11 @@ struct Engine {
   // solve (I - gamma F(Q*)) x = b with left-preconditioned GMRES(m); x holds the initial guess.
   // Convergence: ||M r|| <= rtol * ||M r0||  (PETSc default for the SNES-ksponly linear solve the
   // reference performs: relative to the residual at the warm start)
-  int gmres(const double* qstar, double gamma, int didx, const double* b, double* x) {
+  int gmres(const double* qstar, double gamma, int didx, const double* b, double* x, double rtol = -1.0,
+            int maxit = -1, bool strict = true) {
     const int m = std::min(std::max(1, cfg.gmres_restart), MAXV - 1);
-    const double rtol = cfg.tent_rtol;
+    if (rtol < 0) rtol = cfg.tent_rtol;
+    if (maxit < 0) maxit = cfg.tent_maxit;
     int its = 0;
     double beta0 = -1.0;
     std::vector<double> H((size_t)(m + 1) * m, 0.0), cs(m), sn(m), gv(m + 1);
@@ -508,7 +523,7 @@ struct Engine {
         its++;
         double res = std::fabs(gv[j + 1]);
         if (res <= rtol * beta0 || hn == 0.0) { j++; done = true; break; }
-        if (its >= cfg.tent_maxit) { j++; done = false; break; }
+        if (its >= maxit) { j++; done = false; break; }
       }
       Coefs yc;
       std::vector<double> y(j, 0.0);
@@ -520,7 +535,10 @@ struct Engine {
       for (int l = 0; l < j; l++) yc.c[l] = y[l];
       k_basis_axpy<MAXV><<<nvb, 256, 0, stream>>>(NQ, x, d_gmV, yc, j);
       if (done) return its;
-      if (its >= cfg.tent_maxit) throw NotConverged{"tentative-velocity GMRES reached max iterations"};
+      if (its >= maxit) {
+        if (strict) throw NotConverged{"tentative-velocity GMRES reached max iterations"};
+        return its;
+      }
     }
   }
 
@@ -622,32 +640,59 @@ struct Engine {
         n /= 2;
       }
     }
-    // largest eigenvalue of Dinv * (-S) by power iteration (PETSc estimates it with a few GMRES
-    // steps and uses [0.1, 1.1] * lambda_max as Chebyshev interval)
-    {
-      long ne = (long)g.nx * (g.ny + 1) + (long)(g.nx + 1) * g.ny + (long)g.nx * g.ny;
-      std::vector<double> rnd((size_t)ne * NL);
-      unsigned long long st = 88172645463325252ULL;
-      for (auto& v : rnd) { st ^= st << 13; st ^= st >> 7; st ^= st << 17; v = (double)(st % 2000001ULL) / 1.0e6 - 1.0; }
-      HIPCHECK(hipMemcpyAsync(hL_dev, rnd.data(), sizeof(double) * rnd.size(), hipMemcpyHostToDevice, stream));
-      l_to_modal(hL_dev, cg_p);
-      double lam = 1.0;
-      for (int it = 0; it < 20; it++) {
-        double nrm = std::sqrt(dot(NLv, cg_p, cg_p));
-        axpby(NLv, 0.0, cg_p, 1.0 / nrm, cg_p);
-        trace_apply(cg_p, nullptr, 0.0, 1.0, cg_Ap);
-        zero(cg_z, NLv);
-        trace_cheb(cg_Ap, ch_d, cg_z, 0.0, 1.0);
-        lam = std::sqrt(dot(NLv, cg_z, cg_z));
-        copy(cg_p, cg_z, NLv);
-      }
-      cheb_lmax = 1.1 * lam;
-      cheb_lmin = 0.1 * lam;
+    psets.push_back(PSet{dt, 0.0, 0.0, cfg.tau});
+    estimate_cheb(0);
+    use_pset(0);
+  }
+  // largest eigenvalue of Dinv * (-S) by power iteration (PETSc estimates it with a few GMRES
+  // steps and uses [0.1, 1.1] * lambda_max as Chebyshev interval)
+  void estimate_cheb(int idx) {
+    int saved = cur_pset;
+    cur_pset = idx;
+    long ne = n_edges();
+    std::vector<double> rnd((size_t)ne * NL);
+    unsigned long long st = 88172645463325252ULL;
+    for (auto& v : rnd) { st ^= st << 13; st ^= st >> 7; st ^= st << 17; v = (double)(st % 2000001ULL) / 1.0e6 - 1.0; }
+    HIPCHECK(hipMemcpyAsync(hL_dev, rnd.data(), sizeof(double) * rnd.size(), hipMemcpyHostToDevice, stream));
+    l_to_modal(hL_dev, cg_p);
+    double lam = 1.0;
+    for (int it = 0; it < 20; it++) {
+      double nrm = std::sqrt(dot(NLv, cg_p, cg_p));
+      axpby(NLv, 0.0, cg_p, 1.0 / nrm, cg_p);
+      trace_apply(cg_p, nullptr, 0.0, 1.0, cg_Ap);
+      zero(cg_z, NLv);
+      trace_cheb(cg_Ap, ch_d, cg_z, 0.0, 1.0);
+      lam = std::sqrt(dot(NLv, cg_z, cg_z));
+      copy(cg_p, cg_z, NLv);
     }
+    psets[idx].lmax = 1.1 * lam;
+    psets[idx].lmin = 0.1 * lam;
+    cur_pset = saved;
+  }
+  // operator set for a stabilisation parameter tau' (created on first use)
+  int get_pset(double tau_) {
+    for (size_t i = 0; i < psets.size(); i++)
+      if (std::fabs(psets[i].tau - tau_) <= 1e-14 * std::fabs(tau_)) return (int)i;
+    PSet ps{dt, 0.0, 0.0, tau_};
+    dvec SKh[2];
+    for (int sh = 0; sh < 2; sh++) {
+      dvec Ai, W_, Y_;
+      tab->poissonBlock(sh, tau_, Ai, W_, Y_, SKh[sh]);
+      ps.dt.Ainv[sh] = upload(Ai); ps.dt.W[sh] = upload(W_); ps.dt.Y[sh] = upload(Y_); ps.dt.SK[sh] = upload(SKh[sh]);
+    }
+    dvec tri[3][3];
+    tab->traceBlockInverses(SKh, tri);
+    for (int t = 0; t < 3; t++) for (int v = 0; v < 3; v++) ps.dt.trDinv[t][v] = upload(tri[t][v]);
+    ps.dt.tau = tau_;
+    psets.push_back(ps);
+    estimate_cheb((int)psets.size() - 1);
+    return (int)psets.size() - 1;
   }
   // preconditioned CG on (-S) x = b from the initial guess in x; returns iterations.
   // Convergence on the preconditioned residual norm relative to its initial value (hdg_imex.py:136-137).
-  int trace_cg(double* b, double* x) {
+  int trace_cg(double* b, double* x, double rtol = -1.0, int maxit = -1, bool strict = true) {
+    if (rtol < 0) rtol = cfg.trace_rtol;
+    if (maxit < 0) maxit = cfg.trace_maxit;
     project_const(b);
     trace_apply(x, b, 1.0, -1.0, cg_r);  // r = b - T x
     trace_precond(cg_r, cg_z);
@@ -671,12 +716,142 @@ struct Engine {
       multidot(NLv, cg_z, {cg_r, cg_z}, d2);
       its++;
       double nrm = std::sqrt(d2[1]);
-      if (nrm <= cfg.trace_rtol * norm0) return its;
-      if (its >= cfg.trace_maxit) throw NotConverged{"trace CG reached max iterations"};
+      if (nrm <= rtol * norm0) return its;
+      if (its >= maxit) {
+        if (strict) throw NotConverged{"trace CG reached max iterations"};
+        return its;
+      }
       double beta = d2[0] / rz;
       rz = d2[0];
       axpby(NLv, 1.0, cg_z, beta, cg_p);
     }
+  }
+
+
+  // ------------------------------------------------------------------ unsplit (monolithic) solve
+  // System (hdg_imex.py:602-620; hdg_implicit.py:153-185), gamma = a_ii dt (or dt):
+  //     [ A    -gamma G ] [u]   [r]        A = I - gamma F(Q*),  G y = g(w; phi, lambda)
+  //     [ D_u    D_y    ] [y] = [0]        (D_u, D_y) = rows of Gamma(psi, mu; u, phi, lambda)
+  // The reference factorises the assembled matrix with MUMPS.  Here: flexible GMRES on the full
+  // system, right-preconditioned by the block factorisation with A^{-1} ~ inexact tentative-velocity
+  // solve and the pressure Schur complement ~ hybridised mixed Poisson operator with
+  // stabilisation tau' = tau/gamma acting on y' = gamma y  (D_y is linear in tau):
+  //     u~ = A^{-1} r_u ;  K_mp(tau') (du, y') = (0, r_y - D_u u~) ;  u = u~ + du ;  y = y'/gamma
+  struct V3 { double *u, *p, *l; };
+  std::vector<V3> fg_V, fg_Z;
+  V3 fg_r{nullptr, nullptr, nullptr}, fg_w{nullptr, nullptr, nullptr}, fg_b{nullptr, nullptr, nullptr};
+  V3 alloc3() { return V3{dalloc(NQ), dalloc(NPv), dalloc(NLv)}; }
+  double dot3(const V3& a, const V3& b) { return dot(NQ, a.u, b.u) + dot(NPv, a.p, b.p) + dot(NLv, a.l, b.l); }
+  void axpby3(double a, const V3& x, double b, V3& y) { axpby(NQ, a, x.u, b, y.u); axpby(NPv, a, x.p, b, y.p); axpby(NLv, a, x.l, b, y.l); }
+  void copy3(V3& d, const V3& s_) { copy(d.u, s_.u, NQ); copy(d.p, s_.p, NPv); copy(d.l, s_.l, NLv); }
+  void mono_apply(const V3& x, const double* qstar, double gamma, V3& out) {
+    adv_apply(x.u, qstar, wQ1, gamma);
+    pgrad(wQ1, 1.0, nullptr, 0.0, x.p, x.l, -gamma, out.u);
+    gamma_psi(x.u, x.p, x.l, out.p);
+    gamma_mu(x.u, x.p, x.l, out.l);
+  }
+  void mono_precond(const V3& r, const double* qstar, double gamma, int didx, int psidx, V3& z) {
+    zero(z.u, NQ);
+    gmres(qstar, gamma, didx, r.u, z.u, cfg.unsplit_inner_rtol, 200, false);
+    gamma_psi(z.u, nullptr, nullptr, wP1);
+    axpby(NPv, 1.0, r.p, -1.0, wP1);
+    gamma_mu(z.u, nullptr, nullptr, wL2);
+    axpby(NLv, 1.0, r.l, -1.0, wL2);
+    use_pset(psidx);
+    condense(nullptr, wP1, wL2, wL1);
+    zero(z.l, NLv);
+    trace_cg(wL1, z.l, cfg.unsplit_inner_rtol, 200, false);
+    backsub(nullptr, wP1, z.l, wQ3, z.p);
+    use_pset(0);
+    axpby(NQ, 1.0, wQ3, 1.0, z.u);
+    axpby(NPv, 0.0, z.p, 1.0 / gamma, z.p);
+    axpby(NLv, 0.0, z.l, 1.0 / gamma, z.l);
+  }
+  // flexible GMRES(m); x holds the initial guess; convergence on ||b - K x|| relative to its initial value
+  int fgmres(const double* qstar, double gamma, int didx, int psidx, const V3& b, V3& x) {
+    const int m = std::max(1, cfg.unsplit_restart);
+    if ((int)fg_V.size() < m + 1) {
+      while ((int)fg_V.size() < m + 1) fg_V.push_back(alloc3());
+      while ((int)fg_Z.size() < m) fg_Z.push_back(alloc3());
+      fg_r = alloc3(); fg_w = alloc3();
+    }
+    const double rtol = cfg.unsplit_rtol;
+    std::vector<double> H((size_t)(m + 1) * m, 0.0), cs(m), sn(m), gv(m + 1);
+    int its = 0;
+    double beta0 = -1.0;
+    while (true) {
+      mono_apply(x, qstar, gamma, fg_r);
+      axpby3(1.0, b, -1.0, fg_r);
+      double beta = std::sqrt(dot3(fg_r, fg_r));
+      if (beta0 < 0) beta0 = beta;
+      if (!(beta == beta)) throw NotConverged{"unsplit FGMRES: NaN residual"};
+      if (beta <= rtol * beta0 || beta == 0.0) return its;
+      copy3(fg_V[0], fg_r);
+      axpby3(0.0, fg_r, 1.0 / beta, fg_V[0]);
+      std::fill(gv.begin(), gv.end(), 0.0);
+      gv[0] = beta;
+      int j = 0;
+      bool done = false;
+      for (; j < m; j++) {
+        mono_precond(fg_V[j], qstar, gamma, didx, psidx, fg_Z[j]);
+        mono_apply(fg_Z[j], qstar, gamma, fg_w);
+        for (int l = 0; l <= j; l++) {  // modified Gram-Schmidt
+          double h = dot3(fg_w, fg_V[l]);
+          H[(size_t)l * m + j] = h;
+          axpby3(-h, fg_V[l], 1.0, fg_w);
+        }
+        double hn = std::sqrt(dot3(fg_w, fg_w));
+        H[(size_t)(j + 1) * m + j] = hn;
+        if (hn > 0) { copy3(fg_V[j + 1], fg_w); axpby3(0.0, fg_w, 1.0 / hn, fg_V[j + 1]); }
+        for (int l = 0; l < j; l++) {
+          double a1 = H[(size_t)l * m + j], a2 = H[(size_t)(l + 1) * m + j];
+          H[(size_t)l * m + j] = cs[l] * a1 + sn[l] * a2;
+          H[(size_t)(l + 1) * m + j] = -sn[l] * a1 + cs[l] * a2;
+        }
+        double a1 = H[(size_t)j * m + j], a2 = H[(size_t)(j + 1) * m + j];
+        double rr = std::hypot(a1, a2);
+        cs[j] = (rr == 0) ? 1.0 : a1 / rr;
+        sn[j] = (rr == 0) ? 0.0 : a2 / rr;
+        H[(size_t)j * m + j] = rr;
+        H[(size_t)(j + 1) * m + j] = 0.0;
+        gv[j + 1] = -sn[j] * gv[j];
+        gv[j] = cs[j] * gv[j];
+        its++;
+        if (std::fabs(gv[j + 1]) <= rtol * beta0 || hn == 0.0) { j++; done = true; break; }
+        if (its >= cfg.unsplit_maxit) { j++; break; }
+      }
+      std::vector<double> y(j, 0.0);
+      for (int l = j - 1; l >= 0; l--) {
+        double acc = gv[l];
+        for (int q = l + 1; q < j; q++) acc -= H[(size_t)l * m + q] * y[q];
+        y[l] = acc / H[(size_t)l * m + l];
+      }
+      for (int l = 0; l < j; l++) axpby3(y[l], fg_Z[l], 1.0, x);
+      if (done) {
+        // confirm with the true residual (the inner solves are inexact)
+        mono_apply(x, qstar, gamma, fg_r);
+        axpby3(1.0, b, -1.0, fg_r);
+        if (std::sqrt(dot3(fg_r, fg_r)) <= 10.0 * rtol * beta0) return its;
+      }
+      if (its >= cfg.unsplit_maxit) throw NotConverged{"unsplit FGMRES reached max iterations"};
+    }
+  }
+  // stage i of the IMEX scheme without the projection method (hdg_imex.py:600-620)
+  int unsplit_solve(int i) {
+    if (i < 1 || i >= s) throw std::string("stage out of range");
+    const double gamma = cfg.a_impl[i * s + i] * cfg.dt;
+    ensure_dinv(i, gamma);
+    const int ps = get_pset(cfg.tau / gamma);
+    if (!fg_b.u) fg_b = alloc3();
+    std::vector<double> cq, cb;
+    residual_coeffs(i, cq, cb);
+    residual_vector(cq, cb, fg_b.u);
+    zero(fg_b.p, NPv);
+    zero(fg_b.l, NLv);
+    V3 x{stQ[i], stP[i], stL[i]};
+    int its = fgmres(Qstar[i - 1], gamma, i, ps, fg_b, x);
+    it_sum[0] += its; it_cnt[0]++;
+    return its;
   }
 
   int pressure_solve(int key) {
@@ -732,15 +907,18 @@ struct Engine {
     shift(curP, curL);
   }
   void step() {
-    if (!cfg.use_projection) throw std::string("unsplit (monolithic) stage solve is not implemented");
     begin_step();
     for (int i = 1; i < s; i++) {
       bdm(stQ[i - 1], Qstar[i - 1]);
-      for (int r = 0; r < cfg.n_richardson; r++) {
-        tentative_solve(i);
-        pressure_solve(i);
-        shift(updP, updL);
-        stage_update(i);
+      if (cfg.use_projection) {
+        for (int r = 0; r < cfg.n_richardson; r++) {
+          tentative_solve(i);
+          pressure_solve(i);
+          shift(updP, updL);
+          stage_update(i);
+        }
+      } else {
+        unsplit_solve(i);
       }
       shift(stP[i], stL[i]);
     }
@@ -753,6 +931,21 @@ struct Engine {
     const double dtt = cfg.dt;
     ensure_dinv(0, dtt);
     bdm(curQ, Qstar[0]);                                         // hdg_implicit.py:98
+    if (!cfg.use_projection) {
+      // monolithic (u, phi, lambda) solve, hdg_implicit.py:153-186; fresh Function -> zero guess
+      const int ps = get_pset(cfg.tau / dtt);
+      if (!fg_b.u) fg_b = alloc3();
+      lincomb(NQ, {{curQ, 1.0}, {bvec(0), dtt * bscale[0]}}, fg_b.u);
+      zero(fg_b.p, NPv); zero(fg_b.l, NLv);
+      V3 x{updU, updP, updL};
+      zero(updU, NQ); zero(updP, NPv); zero(updL, NLv);
+      int it = fgmres(Qstar[0], dtt, 0, ps, fg_b, x);
+      copy(curQ, updU, NQ); copy(curP, updP, NPv); copy(curL, updL, NLv);
+      shift(curP, curL);
+      if (its_t) *its_t = it;
+      if (its_p) *its_p = 0;
+      return;
+    }
     // rhs lives in updU: wQ1..wQ4 are scratch of GMRES and its preconditioner
     lincomb(NQ, {{curQ, 1.0}, {bvec(0), dtt * bscale[0]}}, updU);  // (Q,w) + dt (f,w)
     zero(Qtent[0], NQ);
@@ -988,6 +1181,12 @@ int hdg_begin_step(hdg_handle* h) {
 int hdg_tentative_solve(hdg_handle* h, int stage, int* its) {
   HDG_API_BEGIN(h)
   int n = E.tentative_solve(stage);
+  if (its) *its = n;
+  HDG_API_END(h)
+}
+int hdg_unsplit_solve(hdg_handle* h, int stage, int* its) {
+  HDG_API_BEGIN(h)
+  int n = E.unsplit_solve(stage);
   if (its) *its = n;
   HDG_API_END(h)
 }

@@ -700,6 +700,102 @@ __global__ __launch_bounds__(128) void k_precon_rhs(Geo g, DevTables T, const do
 }
 
 // ------------------------------------------------------------------------------------------
+// constraint rows of the monolithic (unsplit) system, Gamma(psi, mu; u, phi, lambda) of hdg_imex.py:342-351
+//   psi-row (per cell):   out = B u + tau * sum_e Pt_e^T (Pt_e phi - lambda_e)
+//   mu-row  (per edge):   out_e = sum_{K contains e} [ sigma N_e u_K + tau Pt_e phi_K - tau lambda_e ]
+// any of u / phi / lam may be null (treated as zero)
+// ------------------------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(128) void k_gamma_psi(Geo g, DevTables T, const double* __restrict__ u,
+                                                    const double* __restrict__ phi, const double* __restrict__ lam,
+                                                    double* __restrict__ out) {
+  constexpr int NU = Dim<K>::NU, NP = Dim<K>::NP, NL = Dim<K>::NL, N2 = 2 * NU;
+  HDG_CELL_PROLOGUE
+  double y[NP];
+#pragma unroll
+  for (int r = 0; r < NP; r++) y[r] = 0.0;
+  if (u) {
+    double x[N2];
+    load_cell<N2>(u, g.Nc, c, x);
+    mv_acc<NP, N2>(T.B[s], x, y, 1.0);
+  }
+  if (phi || lam) {
+    double pp[NP];
+    if (phi) load_cell<NP>(phi, g.Nc, c, pp);
+#pragma unroll
+    for (int e = 0; e < 3; e++) {
+      double tr[NL];
+#pragma unroll
+      for (int m = 0; m < NL; m++) tr[m] = 0.0;
+      if (phi) mv_acc_ld<NL, NP>(T.Pt[s][e], NP, pp, tr, 1.0);
+      if (lam) {
+        int t;
+        const long off = edge_off(s, e, i, j, g, t);
+#pragma unroll
+        for (int m = 0; m < NL; m++) tr[m] -= lam[((long)t * NL + m) * g.G + off];
+      }
+      const double* __restrict__ Pm = T.Pt[s][e];
+#pragma unroll
+      for (int r = 0; r < NP; r++) {
+        double v = 0.0;
+#pragma unroll
+        for (int m = 0; m < NL; m++) v = fma(Pm[m * NP + r], tr[m], v);
+        y[r] = fma(T.tau, v, y[r]);
+      }
+    }
+  }
+  store_cell<NP>(out, g.Nc, c, y);
+}
+
+template <int K>
+__device__ __forceinline__ void gamma_mu_side(const DevTables& T, int s, int e, const double* __restrict__ u,
+                                              const double* __restrict__ phi, long Nc, long c, double* acc) {
+  constexpr int NU = Dim<K>::NU, NP = Dim<K>::NP, NL = Dim<K>::NL, N2 = 2 * NU;
+  if (u) {
+    double x[N2];
+    load_cell<N2>(u, Nc, c, x);
+    mv_acc_ld<NL, N2>(T.N[s][e], N2, x, acc, T.sig[s][e]);
+  }
+  if (phi) {
+    double pp[NP];
+    load_cell<NP>(phi, Nc, c, pp);
+    mv_acc_ld<NL, NP>(T.Pt[s][e], NP, pp, acc, T.tau);
+  }
+}
+
+template <int K>
+__global__ __launch_bounds__(128) void k_gamma_mu(Geo g, DevTables T, const double* __restrict__ u,
+                                                   const double* __restrict__ phi, const double* __restrict__ lam,
+                                                   double* __restrict__ out) {
+  constexpr int NL = Dim<K>::NL;
+  HDG_CORNER_PROLOGUE
+  const long nxy = (long)g.nx * g.ny;
+#pragma unroll
+  for (int t = 0; t < 3; t++) {
+    const int e = (t == 0) ? 0 : (t == 1 ? 2 : 1);
+    bool valid, hasL, hasU;
+    long cL, cU;
+    if (t == 0) { valid = in_x; hasL = in_y; hasU = j > 0; cL = (long)j * g.nx + i; cU = nxy + (long)(j - 1) * g.nx + i; }
+    else if (t == 1) { valid = in_y; hasL = in_x; hasU = i > 0; cL = (long)j * g.nx + i; cU = nxy + (long)j * g.nx + i - 1; }
+    else { valid = in_x && in_y; hasL = hasU = true; cL = (long)j * g.nx + i; cU = nxy + cL; }
+    double acc[NL];
+#pragma unroll
+    for (int m = 0; m < NL; m++) acc[m] = 0.0;
+    if (valid) {
+      if (hasL) gamma_mu_side<K>(T, 0, e, u, phi, g.Nc, cL, acc);
+      if (hasU) gamma_mu_side<K>(T, 1, e, u, phi, g.Nc, cU, acc);
+      if (lam) {
+        const double ncell = (hasL ? 1.0 : 0.0) + (hasU ? 1.0 : 0.0);
+#pragma unroll
+        for (int m = 0; m < NL; m++) acc[m] -= T.tau * ncell * lam[((long)t * NL + m) * g.G + o];
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < NL; m++) out[((long)t * NL + m) * g.G + o] = acc[m];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // nodal <-> modal conversion at the library boundary (array-of-structures, reference layout)
 // ------------------------------------------------------------------------------------------
 // velocity: nodal[(cref*NU + node)*2 + d], cref = 2*(j*nx+i)+s

@@ -434,57 +434,7 @@ struct Tables {
         }
       }
 
-      // ---- hybridised mixed Poisson local block (hdg_imex.py:123-127):
-      //   A = [[I, -B^T],[B, T]],  G = [C^T; -E^T],  H = [C, E],  S_K = -tau I - H A^{-1} G
-      {
-        int n = nx_loc, nt = 3 * nl, n2 = 2 * nu;
-        std::vector<real> A(n * n, 0), G(n * nt, 0), Hm(nt * n, 0);
-        for (int i = 0; i < n2; i++) A[i * n + i] = 1;
-        for (int r = 0; r < np; r++)
-          for (int c = 0; c < n2; c++) {
-            A[(n2 + r) * n + c] = B[s][r * n2 + c];
-            A[c * n + n2 + r] = -(real)B[s][r * n2 + c];
-          }
-        for (int e = 0; e < 3; e++)
-          for (int a = 0; a < nl; a++) {
-            for (int c = 0; c < n2; c++) {
-              real Cv = sig[s][e] * N[s][e][a * n2 + c];
-              Hm[(e * nl + a) * n + c] = Cv;
-              G[c * nt + e * nl + a] = Cv;
-            }
-            for (int m = 0; m < np; m++) {
-              real Ev = tau * Pt[s][e][a * np + m];
-              Hm[(e * nl + a) * n + n2 + m] = Ev;
-              G[(n2 + m) * nt + e * nl + a] = -Ev;
-              for (int m2 = 0; m2 < np; m2++)
-                A[(n2 + m) * n + n2 + m2] += tau * Pt[s][e][a * np + m] * Pt[s][e][a * np + m2];
-            }
-          }
-        invert(n, A);
-        std::vector<real> Wm(n * nt, 0), Ym(nt * n, 0), Sm(nt * nt, 0);
-        for (int i = 0; i < n; i++)
-          for (int j = 0; j < nt; j++) {
-            real acc = 0;
-            for (int l = 0; l < n; l++) acc += A[i * n + l] * G[l * nt + j];
-            Wm[i * nt + j] = acc;
-          }
-        for (int i = 0; i < nt; i++)
-          for (int j = 0; j < n; j++) {
-            real acc = 0;
-            for (int l = 0; l < n; l++) acc += Hm[i * n + l] * A[l * n + j];
-            Ym[i * n + j] = acc;
-          }
-        for (int i = 0; i < nt; i++)
-          for (int j = 0; j < nt; j++) {
-            real acc = (i == j) ? -(real)tau : 0;
-            for (int l = 0; l < n; l++) acc -= Hm[i * n + l] * Wm[l * nt + j];
-            Sm[i * nt + j] = acc;
-          }
-        Ainv[s].assign(A.begin(), A.end());
-        W[s].assign(Wm.begin(), Wm.end());
-        Y[s].assign(Ym.begin(), Ym.end());
-        SK[s].assign(Sm.begin(), Sm.end());
-      }
+      poissonBlock(s, tau, Ainv[s], W[s], Y[s], SK[s]);
     }
 
     // ---- advection quadrature (cell rule exact to 3k+2, edge rule ceil((3k+4)/2) Gauss points:
@@ -537,23 +487,78 @@ struct Tables {
       }
     }
 
-    // ---- trace block-Jacobi: diagonal blocks of -S per edge type (H,V,D) <-> local edge (0,2,1)
-    {
-      const int loc_of_type[3] = {0, 2, 1};
-      int nt = 3 * nl;
-      for (int t = 0; t < 3; t++) {
-        int e = loc_of_type[t];
-        for (int var = 0; var < 3; var++) {
-          std::vector<real> Dm(nl * nl, 0);
-          for (int a = 0; a < nl; a++)
-            for (int b = 0; b < nl; b++) {
-              real v = -(real)SK[0][(e * nl + a) * nt + e * nl + b];
-              real v2 = -(real)SK[1][(e * nl + a) * nt + e * nl + b];
-              Dm[a * nl + b] = (var == 0) ? v + v2 : (var == 1 ? v : v2);
-            }
-          invert(nl, Dm);
-          trDinv[t][var].assign(Dm.begin(), Dm.end());
+    traceBlockInverses(SK, trDinv);
+  }
+
+  // hybridised mixed Poisson local block for stabilisation parameter tau_ (hdg_imex.py:123-127):
+  //   A = [[I, -B^T],[B, T]],  G = [C^T; -E^T],  H = [C, E],  S_K = -tau I - H A^{-1} G
+  void poissonBlock(int s, double tau_, dvec& Ainv_, dvec& W_, dvec& Y_, dvec& SK_) const {
+    int n = nx_loc, nt = 3 * nl, n2 = 2 * nu;
+    std::vector<real> A(n * n, 0), G(n * nt, 0), Hm(nt * n, 0);
+    for (int i = 0; i < n2; i++) A[i * n + i] = 1;
+    for (int r = 0; r < np; r++)
+      for (int c = 0; c < n2; c++) {
+        A[(n2 + r) * n + c] = B[s][r * n2 + c];
+        A[c * n + n2 + r] = -(real)B[s][r * n2 + c];
+      }
+    for (int e = 0; e < 3; e++)
+      for (int a = 0; a < nl; a++) {
+        for (int c = 0; c < n2; c++) {
+          real Cv = sig[s][e] * N[s][e][a * n2 + c];
+          Hm[(e * nl + a) * n + c] = Cv;
+          G[c * nt + e * nl + a] = Cv;
         }
+        for (int m = 0; m < np; m++) {
+          real Ev = (real)tau_ * Pt[s][e][a * np + m];
+          Hm[(e * nl + a) * n + n2 + m] = Ev;
+          G[(n2 + m) * nt + e * nl + a] = -Ev;
+          for (int m2 = 0; m2 < np; m2++)
+            A[(n2 + m) * n + n2 + m2] += (real)tau_ * Pt[s][e][a * np + m] * Pt[s][e][a * np + m2];
+        }
+      }
+    invert(n, A);
+    std::vector<real> Wm(n * nt, 0), Ym(nt * n, 0), Sm(nt * nt, 0);
+    for (int i = 0; i < n; i++)
+      for (int j = 0; j < nt; j++) {
+        real acc = 0;
+        for (int l = 0; l < n; l++) acc += A[i * n + l] * G[l * nt + j];
+        Wm[i * nt + j] = acc;
+      }
+    for (int i = 0; i < nt; i++)
+      for (int j = 0; j < n; j++) {
+        real acc = 0;
+        for (int l = 0; l < n; l++) acc += Hm[i * n + l] * A[l * n + j];
+        Ym[i * n + j] = acc;
+      }
+    for (int i = 0; i < nt; i++)
+      for (int j = 0; j < nt; j++) {
+        real acc = (i == j) ? -(real)tau_ : 0;
+        for (int l = 0; l < n; l++) acc -= Hm[i * n + l] * Wm[l * nt + j];
+        Sm[i * nt + j] = acc;
+      }
+    Ainv_.assign(A.begin(), A.end());
+    W_.assign(Wm.begin(), Wm.end());
+    Y_.assign(Ym.begin(), Ym.end());
+    SK_.assign(Sm.begin(), Sm.end());
+  }
+
+  // trace block-Jacobi: inverse diagonal blocks of -S per edge type (H,V,D) <-> local edge (0,2,1);
+  // variant 0: both cells, 1: L cell only, 2: U cell only
+  void traceBlockInverses(const dvec (&SK_)[2], dvec (&out)[3][3]) const {
+    const int loc_of_type[3] = {0, 2, 1};
+    int nt = 3 * nl;
+    for (int t = 0; t < 3; t++) {
+      int e = loc_of_type[t];
+      for (int var = 0; var < 3; var++) {
+        std::vector<real> Dm(nl * nl, 0);
+        for (int a = 0; a < nl; a++)
+          for (int b = 0; b < nl; b++) {
+            real v = -(real)SK_[0][(e * nl + a) * nt + e * nl + b];
+            real v2 = -(real)SK_[1][(e * nl + a) * nt + e * nl + b];
+            Dm[a * nl + b] = (var == 0) ? v + v2 : (var == 1 ? v : v2);
+          }
+        invert(nl, Dm);
+        out[t][var].assign(Dm.begin(), Dm.end());
       }
     }
   }

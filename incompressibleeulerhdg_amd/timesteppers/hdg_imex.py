@@ -166,7 +166,9 @@ class IncompressibleEulerHDGIMEX(IncompressibleEuler):
                                 self._shift_pressure(_lib.HDG_STATE_UPDATE)
                                 eng.stage_update(i)
                         else:
-                            raise NotImplementedError("unsplit stage solve (hdg_imex.py:600-620)")
+                            with PerformanceLog("unsplit_solve"):
+                                its = eng.unsplit_solve(i)  # hdg_imex.py:600-620
+                            self.niter_tentative.update(its)
                         self._shift_pressure(i)
                     its = self.pressure_solve("final_stage")
                     self.niter_final_pressure.update(its)

@@ -13,8 +13,8 @@ class IncompressibleEulerHDGImplicit(IncompressibleEuler):
     """First order in time; Chorin's projection method (hdg_implicit.py:101-150).
 
     ``n_richardson`` is accepted and ignored so that the reference driver's call shape
-    (driver.py:220-228) works.  The monolithic branch
-    (``use_projection_method=False``, hdg_implicit.py:151-186) is not available in this round.
+    (driver.py:220-228) works.  ``use_projection_method=False`` selects the
+    monolithic (u, phi, lambda) solve of hdg_implicit.py:151-186.
     """
 
     def __init__(self, mesh, degree, dt, flux="upwind", use_projection_method=True, callbacks=None,
@@ -28,15 +28,13 @@ class IncompressibleEulerHDGImplicit(IncompressibleEuler):
         self.tau = 1  # hdg_implicit.py:43
         self.niter_tentative = Averager()
         self.niter_pressure = Averager()
-        self._create_engine(flux=flux, use_projection_method=True, n_richardson=1, tau=self.tau,
+        self._create_engine(flux=flux, use_projection_method=use_projection_method, n_richardson=1, tau=self.tau,
                             alpha_penalty=self.alpha, nstages=1, a_expl=[[0]], a_impl=[[1]], b_expl=[1],
                             b_impl=[1], c_expl=[0])
 
     def solve(self, Q_initial, p_initial, q_initial, f_rhs, T_final, warmup=False):
         if q_initial:
             raise NotImplementedError("passive tracer advection is out of scope")
-        if not self.use_projection_method:
-            raise NotImplementedError("monolithic implicit solve (hdg_implicit.py:151-186)")
         eng = self._engine
         nt = self.get_timesteps(T_final, warmup)
         eng.set_state(self._as_nodal_velocity(Q_initial), self._as_nodal_pressure(p_initial))

@@ -158,3 +158,47 @@ def test_driver_prints_reference_quantities(hip_lib, capsys):
     rc = driver.main(["--nx", "8", "--test_pressure_solver", "--use_projection_method"])
     out = capsys.readouterr().out
     assert rc == 0 and "number of iterations" in out
+
+
+@pytest.mark.parametrize("k,nx,tableau", [(1, 6, "imex_ssp2_332"), (2, 4, "imex_ars2_232"), (1, 6, "imex_implicit")])
+def test_unsplit_stage_solve(hip_lib, k, nx, tableau):
+    """use_projection_method=False: monolithic stage solves (hdg_imex.py:600-620) vs the oracle's
+    bordered sparse LU.  The outer FGMRES stops at 1e-10 relative residual: tolerance 2e-8."""
+    from incompressibleeulerhdg_amd import _lib
+    from incompressibleeulerhdg_amd.mesh import UnitSquareMesh
+    from incompressibleeulerhdg_amd.model_problems import TaylorGreen
+    from oracle import hdg_oracle as orc
+
+    dt = 0.25 / nx
+    ts = _classes()[tableau](UnitSquareMesh(nx, nx), k, dt, use_projection_method=False)
+    mp = TaylorGreen(ts._V_Q, ts._V_p)
+    for fused in (False, True):
+        Q, p = ts.solve(*mp.initial_condition(), None, mp.f_rhs(), 2 * dt, fused=fused)
+        lam = ts._engine.get_field(_lib.HDG_STATE_CURRENT, Q=False, p=False)[2]
+        d = orc.HDGDiscretisation(nx, k)
+        tg = orc.TaylorGreen(d)
+        o = orc.OracleHDGIMEX(d, dt, tableau, use_projection_method=False)
+        oQ, op = o.solve(*tg.initial_condition(), tg.f_rhs, 2 * dt)
+        assert _relerr(Q.dat.data, oQ) < TOL and _relerr(p.dat.data, op) < TOL and _relerr(lam, o.lam) < TOL
+        if fused:
+            break
+        # a fresh instance for the fused run (stage vectors persist inside an instance)
+        ts = _classes()[tableau](UnitSquareMesh(nx, nx), k, dt, use_projection_method=False)
+        mp = TaylorGreen(ts._V_Q, ts._V_p)
+
+
+@pytest.mark.parametrize("k,nx,dt", [(1, 8, 0.02), (1, 16, 0.05)])
+def test_hdg_implicit_monolithic(hip_lib, k, nx, dt):
+    """BASELINE config C1 with the projection method OFF (hdg_implicit.py:151-186)."""
+    from incompressibleeulerhdg_amd.mesh import UnitSquareMesh
+    from incompressibleeulerhdg_amd.model_problems import TaylorGreen
+    from incompressibleeulerhdg_amd.timesteppers import IncompressibleEulerHDGImplicit
+    from oracle import hdg_oracle as orc
+
+    ts = IncompressibleEulerHDGImplicit(UnitSquareMesh(nx, nx), k, dt, use_projection_method=False)
+    mp = TaylorGreen(ts._V_Q, ts._V_p)
+    Q, p = ts.solve(*mp.initial_condition(), None, mp.f_rhs(), 2 * dt)
+    d = orc.HDGDiscretisation(nx, k)
+    tg = orc.TaylorGreen(d)
+    oQ, op = orc.OracleHDGImplicit(d, dt, use_projection_method=False).solve(*tg.initial_condition(), tg.f_rhs, 2 * dt)
+    assert _relerr(Q.dat.data, oQ) < TOL and _relerr(p.dat.data, op) < TOL
