@@ -33,7 +33,8 @@ enum {
   HDG_ERR_HIP = -2,         /* HIP runtime error */
   HDG_ERR_NOT_CONVERGED = -3, /* Krylov hit max iterations or broke down */
   HDG_ERR_SINGULAR = -4,    /* singular local block while building tables */
-  HDG_ERR_UNSUPPORTED = -5
+  HDG_ERR_UNSUPPORTED = -5,
+  HDG_ERR_COMM = -6         /* inter-rank transport error (RCCL / shared memory) */
 };
 
 /* keys of hdg_pressure_solve (timesteppers/hdg_imex.py:258-272: "stage_i", "final_stage",
@@ -86,7 +87,20 @@ int hdg_create(const hdg_config* cfg, hdg_handle** out);
 int hdg_destroy(hdg_handle* h);
 const char* hdg_last_error(const hdg_handle* h); /* h may be NULL for create errors */
 
-/* sizes: n_cells, n_edges, n_u, n_p, n_l */
+/* Strip-partitioned engine, one process per GPU: rank r of nranks owns the
+ * cell rows r*ny/nranks .. (r+1)*ny/nranks - 1 of the global mesh (cfg->ny must be divisible by
+ * nranks); all host arrays of the other entry points then refer to THIS RANK'S STRIP in local
+ * numbering (edge rows 0..ny_local; the top row of a non-top rank duplicates its upper neighbour's
+ * bottom row).  backend HDG_COMM_RCCL: `token` = the 128 bytes from hdg_rccl_unique_id of rank 0
+ * (one GPU per rank); HDG_COMM_SHM: `token` = name of a POSIX shared-memory segment, host-staged
+ * transport for several ranks on one node (also on one GPU).  Reductions are over owned entries and
+ * identical on every rank, so all ranks take the same Krylov iterations. */
+#define HDG_COMM_RCCL 1
+#define HDG_COMM_SHM 2
+int hdg_create_distributed(const hdg_config* cfg, int rank, int nranks, int backend, const char* token, hdg_handle** out);
+int hdg_rccl_unique_id(char* out128);
+
+/* sizes of this rank's strip: n_cells, n_edges, n_u, n_p, n_l */
 int hdg_get_sizes(const hdg_handle* h, long* n_cells, long* n_edges, int* n_u, int* n_p, int* n_l);
 
 /* interpolated initial condition -> _current_state (hdg_imex.py:520-533; hdg_implicit.py:82-84):

@@ -22,7 +22,10 @@ HDG_STATE_CURRENT = 0
 HDG_STATE_UPDATE = -1
 HDG_STATE_RECON = -2
 
-ERRORS = {-1: "HDG_ERR_ARG", -2: "HDG_ERR_HIP", -3: "HDG_ERR_NOT_CONVERGED", -4: "HDG_ERR_SINGULAR", -5: "HDG_ERR_UNSUPPORTED"}
+ERRORS = {-1: "HDG_ERR_ARG", -2: "HDG_ERR_HIP", -3: "HDG_ERR_NOT_CONVERGED", -4: "HDG_ERR_SINGULAR", -5: "HDG_ERR_UNSUPPORTED",
+          -6: "HDG_ERR_COMM"}
+HDG_COMM_RCCL = 1
+HDG_COMM_SHM = 2
 
 
 class HDGError(RuntimeError):
@@ -66,11 +69,12 @@ class hdg_config(C.Structure):
 
 def build_library(force=False, verbose=False):
     """Compile the HIP engine for gfx950 into the package directory (in-tree, travels with gpurun)."""
-    srcs = [SRC, HEADER] + [os.path.join(_HERE, "csrc", f) for f in ("hdg_kernels.hpp", "hdg_tables.hpp")]
+    srcs = [SRC, HEADER] + [os.path.join(_HERE, "csrc", f) for f in ("hdg_kernels.hpp", "hdg_tables.hpp", "hdg_comm.hpp")]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-o", LIB_PATH, SRC]
+    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-o", LIB_PATH, SRC,
+           "-L/opt/rocm/lib", "-lrccl", "-lrt", "-lpthread"]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
@@ -87,6 +91,8 @@ _h = C.c_void_p
 # every symbol include/hdg_mi355x.h declares, with its argument types
 SIGNATURES = {
     "hdg_create": [C.POINTER(hdg_config), C.POINTER(_h)],
+    "hdg_create_distributed": [C.POINTER(hdg_config), C.c_int, C.c_int, C.c_int, C.c_char_p, C.POINTER(_h)],
+    "hdg_rccl_unique_id": [C.c_char_p],
     "hdg_destroy": [_h],
     "hdg_get_sizes": [_h, _lp, _lp, _ip, _ip, _ip],
     "hdg_set_state": [_h, _dp, _dp],
@@ -196,7 +202,14 @@ class Engine:
         cfg.device = int(kw.get("device", 0))
         self.cfg = cfg
         self.h = _h()
-        rc = self.lib.hdg_create(C.byref(cfg), C.byref(self.h))
+        self.rank, self.nranks = int(kw.get("rank", 0)), int(kw.get("nranks", 1))
+        if self.nranks > 1:
+            backend = {"rccl": HDG_COMM_RCCL, "shm": HDG_COMM_SHM}[kw.get("comm_backend", "rccl")]
+            token = kw["comm_token"]
+            token = token if isinstance(token, bytes) else str(token).encode()
+            rc = self.lib.hdg_create_distributed(C.byref(cfg), self.rank, self.nranks, backend, token, C.byref(self.h))
+        else:
+            rc = self.lib.hdg_create(C.byref(cfg), C.byref(self.h))
         if rc != 0:
             raise HDGError(rc, self.lib.hdg_last_error(None).decode())
         nc, ne = C.c_long(), C.c_long()
@@ -208,8 +221,9 @@ class Engine:
         self.shape_Q = (self.n_cells * self.n_u, 2)
         self.shape_p = (self.n_cells * self.n_p,)
         self.shape_l = (self.n_edges * self.n_l,)
-        # dimension of the mixed state (Q, p, lambda) advanced per step
-        self.n_total = self.n_cells * (2 * self.n_u + self.n_p) + self.n_edges * self.n_l
+        # dimension of the GLOBAL mixed state (Q, p, lambda) advanced per step
+        nxg, nyg = cfg.nx, cfg.ny
+        self.n_total = 2 * nxg * nyg * (2 * self.n_u + self.n_p) + (3 * nxg * nyg + nxg + nyg) * self.n_l
 
     def _ck(self, rc):
         if rc != 0:

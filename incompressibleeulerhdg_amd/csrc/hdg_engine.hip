@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "../../include/hdg_mi355x.h"
+#include "hdg_comm.hpp"
 #include "hdg_kernels.hpp"
 #include "hdg_tables.hpp"
 
@@ -52,7 +53,12 @@ struct Engine {
   hdg_config cfg;
   Geo g;
   int K, NU, NP, NL, NE, NX, s;
-  long NQ, NPv, NLv;  // vector lengths: velocity, pressure, trace (padded)
+  long NQ, NPv, NLv;  // vector lengths incl. ghost rows: velocity, pressure, trace (padded)
+  long NQb, NPb, NLb;  // lengths of the nodal arrays at the C boundary (this rank's strip, no ghosts)
+  Comm* comm = nullptr;
+  Geo g_all;           // same strip, but corner kernels visit every local row 0..ny (conversions)
+  double *hb_slo = nullptr, *hb_shi = nullptr, *hb_rlo = nullptr, *hb_rhi = nullptr;  // halo buffers
+  double* mg_gather = nullptr;
   Tables* tab = nullptr;
   DevTables dt;
   hipStream_t stream = nullptr;
@@ -135,11 +141,12 @@ struct Engine {
 
   dim3 cell_grid() const { return dim3(8 * g.rows_xcd * 2 * g.nbx, 1, 1); }
   dim3 corner_grid() const { return dim3(8 * g.rows_xcdc * g.nbxc, 1, 1); }
+  dim3 corner_grid_all() const { return dim3(8 * g_all.rows_xcdc * g_all.nbxc, 1, 1); }
   int bs() const { return g.nx <= 64 ? 64 : 128; }
   int vec_blocks(long n) const { return (int)std::min<long>((n + 255) / 256, 2048); }
 
   // ------------------------------------------------------------------ construction
-  explicit Engine(const hdg_config& c) : cfg(c) {
+  Engine(const hdg_config& c, Comm* comm_) : cfg(c), comm(comm_) {
     if (c.degree < 1 || c.degree > 4) throw std::string("degree must be in 1..4");
     if (c.nx < 1 || c.ny < 1) throw std::string("nx, ny must be positive");
     if (c.nx != c.ny) throw std::string("only square meshes nx == ny (UnitSquareMesh(nx, nx), driver.py:181)");
@@ -150,16 +157,25 @@ struct Engine {
     K = c.degree;
     s = c.nstages;
     NU = n_scalar(K + 1); NP = n_scalar(K); NL = K + 1; NE = K + 2; NX = 2 * NU + NP;
-    g.nx = c.nx; g.ny = c.ny;
+    if (c.ny % comm->size != 0) throw std::string("ny must be divisible by the number of ranks (strip partition)");
+    g.nx = c.nx; g.nyg = c.ny;
+    g.ny = c.ny / comm->size;
+    g.joff = comm->rank * g.ny;
+    g.nyc = g.ny + (comm->rank == comm->size - 1 ? 1 : 0);
     g.P = ((c.nx + 1 + 15) / 16) * 16;
-    g.G = (long)(c.ny + 1) * g.P;
-    g.Nc = 2L * c.nx * c.ny;
+    g.G = (long)(g.ny + 2) * g.P;
+    g.Nc = 2L * c.nx * (g.ny + 2);
     g.h = 1.0 / c.nx;
     g.nbx = (g.nx + bs() - 1) / bs();
     g.nbxc = (g.nx + 1 + bs() - 1) / bs();
     g.rows_xcd = (g.ny + 7) / 8;
-    g.rows_xcdc = (g.ny + 1 + 7) / 8;
+    g.rows_xcdc = (g.nyc + 7) / 8;
+    g_all = g;
+    g_all.nyc = g.ny + 1;
+    g_all.rows_xcdc = (g_all.nyc + 7) / 8;
     NQ = 2L * NU * g.Nc; NPv = (long)NP * g.Nc; NLv = 3L * NL * g.G;
+    NQb = 2L * NU * 2L * g.nx * g.ny; NPb = (long)NP * 2L * g.nx * g.ny;
+    NLb = n_edges() * NL;
     tab = new Tables(K, g.h, c.tau, c.alpha_penalty, c.equispaced_nodes);
     build_dev_tables();
     alloc_state();
@@ -170,6 +186,7 @@ struct Engine {
     for (void* p : allocs) (void)hipFree(p);
     if (stream) (void)hipStreamDestroy(stream);
     delete tab;
+    delete comm;
   }
 
   void build_dev_tables() {
@@ -239,9 +256,12 @@ struct Engine {
     d_part = dalloc((long)dot_blocks * MAXV);
     d_res = dalloc(MAXV);
     d_coef = dalloc(MAXV);
-    hQ_dev = dalloc(NQ); hP_dev = dalloc(NPv);
-    long ne = (long)g.nx * (g.ny + 1) + (long)(g.nx + 1) * g.ny + (long)g.nx * g.ny;
-    hL_dev = dalloc(ne * NL);
+    hQ_dev = dalloc(NQb); hP_dev = dalloc(NPb);
+    hL_dev = dalloc(NLb);
+    {
+      long cap = std::max<long>(2L * NU * 2L * g.nx, 3L * NL * g.P);
+      hb_slo = dalloc(cap); hb_shi = dalloc(cap); hb_rlo = dalloc(cap); hb_rhi = dalloc(cap);
+    }
     for (int i = 0; i < s; i++) { dinv0.push_back(nullptr); dinv1.push_back(nullptr); dinv_gamma.push_back(-1.0); }
   }
 
@@ -254,17 +274,39 @@ struct Engine {
     case 4: { constexpr int KK = 4; __VA_ARGS__; } break; \
   }
 
+  // ------------------------------------------------------------------ halo rows (strip partition)
+  // Policy: every stencil operator refreshes the ghost rows of the vectors whose neighbour values it
+  // reads; kernels write owned rows only.  (Pure vector updates act on ghosts too, which keeps
+  // consistent copies consistent.)
+  void halo_rows(double* v, long plane_stride, int row_len, int nplanes) {
+    if (comm->size == 1) return;
+    const long n = (long)nplanes * row_len;
+    const int nb = vec_blocks(n);
+    k_pack_rows<<<nb, 256, 0, stream>>>(v, plane_stride, row_len, nplanes, 1, hb_slo);
+    k_pack_rows<<<nb, 256, 0, stream>>>(v, plane_stride, row_len, nplanes, g.ny, hb_shi);
+    comm->exchange(hb_slo, hb_rlo, hb_shi, hb_rhi, (size_t)n, stream);
+    if (comm->rank > 0) k_unpack_rows<<<nb, 256, 0, stream>>>(v, plane_stride, row_len, nplanes, 0, hb_rlo);
+    if (comm->rank < comm->size - 1) k_unpack_rows<<<nb, 256, 0, stream>>>(v, plane_stride, row_len, nplanes, g.ny + 1, hb_rhi);
+  }
+  void halo_Q(const double* v) { halo_rows(const_cast<double*>(v), (long)(g.ny + 2) * g.nx, g.nx, 2 * NU * 2); }
+  void halo_P(const double* v) { halo_rows(const_cast<double*>(v), (long)(g.ny + 2) * g.nx, g.nx, NP * 2); }
+  void halo_L(const double* v) { halo_rows(const_cast<double*>(v), g.G, g.P, 3 * NL); }
+
   void bdm(const double* in, double* out) {
+    halo_Q(in);
     HDG_DISPATCH(k_edge_lift<KK, false, false><<<cell_grid(), bs(), 0, stream>>>(g, dt, in, out, nullptr, nullptr, nullptr));
   }
   // out = Pi(in) + Dinv r   (second half of the two-level preconditioner, block-Jacobi fused in)
   void bdm_plus_bj(const double* in, double* out, const double* r, const double* D0, const double* D1) {
+    halo_Q(in);
     HDG_DISPATCH(k_edge_lift<KK, false, true><<<cell_grid(), bs(), 0, stream>>>(g, dt, in, out, r, D0, D1));
   }
   void bdm_T(const double* in, double* out) {
+    halo_Q(in);
     HDG_DISPATCH(k_edge_lift<KK, true, false><<<cell_grid(), bs(), 0, stream>>>(g, dt, in, out, nullptr, nullptr, nullptr));
   }
   void adv_apply(const double* x, const double* qstar, double* out, double gamma) {
+    halo_Q(x);
     const double up = cfg.flux_upwind ? 1.0 : 0.0;
     HDG_DISPATCH(k_adv_apply<KK><<<cell_grid(), bs(), 0, stream>>>(g, dt, x, qstar, out, gamma, up));
   }
@@ -273,38 +315,51 @@ struct Engine {
   }
   void pgrad(const double* a, double ca, const double* b, double cb, const double* p, const double* l, double gamma,
              double* out) {
+    halo_L(l);
     HDG_DISPATCH(k_pgrad<KK><<<cell_grid(), bs(), 0, stream>>>(g, dt, a, ca, b, cb, p, l, gamma, out));
   }
   void weak_div(const double* q, double sc, double* out, bool broken) {
+    if (!broken) halo_Q(q);
     if (broken) { HDG_DISPATCH(k_weak_div<KK, true><<<cell_grid(), bs(), 0, stream>>>(g, dt, q, sc, out)); }
     else { HDG_DISPATCH(k_weak_div<KK, false><<<cell_grid(), bs(), 0, stream>>>(g, dt, q, sc, out)); }
   }
   void trace_apply(const double* lam, const double* base, double cb, double ct, double* out) {
+    halo_L(lam);
     HDG_DISPATCH(k_trace_apply<KK><<<corner_grid(), bs(), 0, stream>>>(g, pdt(), lam, base, cb, ct, out));
   }
   void trace_cheb(const double* r, double* d, double* x, double c1, double c2) {
     HDG_DISPATCH(k_trace_cheb<KK><<<corner_grid(), bs(), 0, stream>>>(g, pdt(), r, d, x, c1, c2));
   }
   void condense(const double* rw, const double* rp, const double* rl, double* out) {
+    if (rw) halo_Q(rw);
+    if (rp) halo_P(rp);
     if (rw && !rp) { HDG_DISPATCH(k_condense<KK, true, false><<<corner_grid(), bs(), 0, stream>>>(g, pdt(), rw, rp, rl, out)); }
     else if (!rw && rp) { HDG_DISPATCH(k_condense<KK, false, true><<<corner_grid(), bs(), 0, stream>>>(g, pdt(), rw, rp, rl, out)); }
     else { HDG_DISPATCH(k_condense<KK, true, true><<<corner_grid(), bs(), 0, stream>>>(g, pdt(), rw, rp, rl, out)); }
   }
   void backsub(const double* rw, const double* rp, const double* lam, double* u, double* phi) {
+    halo_L(lam);
     if (rw && !rp) { HDG_DISPATCH(k_backsub<KK, true, false><<<cell_grid(), bs(), 0, stream>>>(g, pdt(), rw, rp, lam, u, phi)); }
     else if (!rw && rp) { HDG_DISPATCH(k_backsub<KK, false, true><<<cell_grid(), bs(), 0, stream>>>(g, pdt(), rw, rp, lam, u, phi)); }
     else { HDG_DISPATCH(k_backsub<KK, true, true><<<cell_grid(), bs(), 0, stream>>>(g, pdt(), rw, rp, lam, u, phi)); }
   }
   void gamma_psi(const double* u, const double* phi, const double* lam, double* out) {
+    if (lam) halo_L(lam);
     HDG_DISPATCH(k_gamma_psi<KK><<<cell_grid(), bs(), 0, stream>>>(g, dt, u, phi, lam, out));
   }
   void gamma_mu(const double* u, const double* phi, const double* lam, double* out) {
+    if (u) halo_Q(u);
+    if (phi) halo_P(phi);
     HDG_DISPATCH(k_gamma_mu<KK><<<corner_grid(), bs(), 0, stream>>>(g, dt, u, phi, lam, out));
   }
   void trace_recon(const double* Q, const double* p, double* out) {
+    halo_Q(Q);
+    halo_P(p);
     HDG_DISPATCH(k_trace_recon<KK><<<corner_grid(), bs(), 0, stream>>>(g, dt, Q, p, out));
   }
   void precon_rhs(const double* Q, const double* b, double bsc, double* rp, double* rl) {
+    halo_Q(Q);
+    halo_Q(b);
     HIPCHECK(hipMemsetAsync(rl, 0, sizeof(double) * NLv, stream));
     HDG_DISPATCH(k_precon_rhs<KK><<<cell_grid(), bs(), 0, stream>>>(g, dt, Q, b, bsc, rp, rl));
   }
@@ -314,9 +369,9 @@ struct Engine {
   void p_to_nodal(const double* modal, double* nodal) { HDG_DISPATCH(k_p_modal_to_nodal<KK><<<cell_grid(), bs(), 0, stream>>>(g, dt, modal, nodal)); }
   void l_to_modal(double* nodal, double* modal) {
     HIPCHECK(hipMemsetAsync(modal, 0, sizeof(double) * NLv, stream));
-    HDG_DISPATCH(k_l_convert<KK, true><<<corner_grid(), bs(), 0, stream>>>(g, dt, nodal, modal));
+    HDG_DISPATCH(k_l_convert<KK, true><<<corner_grid_all(), bs(), 0, stream>>>(g_all, dt, nodal, modal));
   }
-  void l_to_nodal(double* modal, double* nodal) { HDG_DISPATCH(k_l_convert<KK, false><<<corner_grid(), bs(), 0, stream>>>(g, dt, nodal, modal)); }
+  void l_to_nodal(double* modal, double* nodal) { HDG_DISPATCH(k_l_convert<KK, false><<<corner_grid_all(), bs(), 0, stream>>>(g_all, dt, nodal, modal)); }
 
   // ------------------------------------------------------------------ vector helpers
   void copy(double* dst, const double* src, long n) {
@@ -347,22 +402,29 @@ struct Engine {
       first = false;
     }
   }
-  // dots of w against nv vectors (host result); one sync
-  void multidot(long n, const double* w, const std::vector<const double*>& V, double* res) {
+  // ownership mask for a vector of length n (cell-type or trace-type row structure)
+  enum { KC = 1, KL = 2 };  // row structure of a vector: cell-type (velocity, pressure) or trace-type
+  RowMask mask_for(int kind) const {
+    if (kind == KL) return RowMask{g.P, g.ny + 2, 1, g.nyc};
+    return RowMask{g.nx, g.ny + 2, 1, g.ny};
+  }
+  // dots of w against nv vectors over the OWNED entries, summed over ranks (host result); one sync
+  void multidot(long n, const double* w, const std::vector<const double*>& V, double* res, int kind) {
     int nv = (int)V.size();
     for (int off = 0; off < nv; off += MAXV) {
       int cnt = std::min(MAXV, nv - off);
       HIPCHECK(hipMemcpyAsync((void*)d_ptrs, V.data() + off, sizeof(double*) * cnt, hipMemcpyHostToDevice, stream));
       int nb = std::min(dot_blocks, vec_blocks(n));
-      k_multidot<MAXV><<<nb, HDG_DOT_BLOCK, 0, stream>>>(n, w, d_ptrs, cnt, d_part);
+      k_multidot<MAXV><<<nb, HDG_DOT_BLOCK, 0, stream>>>(n, w, d_ptrs, cnt, d_part, mask_for(kind));
       k_reduce_parts<<<cnt, 256, 0, stream>>>(nb, cnt, d_part, d_res);
+      comm->allreduce_sum(d_res, cnt, stream);
       HIPCHECK(hipMemcpyAsync(res + off, d_res, sizeof(double) * cnt, hipMemcpyDeviceToHost, stream));
       HIPCHECK(hipStreamSynchronize(stream));
     }
   }
-  double dot(long n, const double* a, const double* b) {
+  double dot(long n, const double* a, const double* b, int kind) {
     double r;
-    multidot(n, a, {b}, &r);
+    multidot(n, a, {b}, &r, kind);
     return r;
   }
   void multiaxpy(long n, double* w, const std::vector<const double*>& V, const std::vector<double>& h, double sign) {
@@ -381,8 +443,9 @@ struct Engine {
     const double c0 = g.h / std::sqrt(2.0);  // integral of the mode-0 basis function = its "1" coefficient
     const double vol = 1.0;                  // domain_volume (common.py:72-73)
     int nb = std::min(dot_blocks, vec_blocks(g.Nc));
-    k_multidot<MAXV><<<nb, HDG_DOT_BLOCK, 0, stream>>>(g.Nc, p, d_ones_ptr, 1, d_part);
+    k_multidot<MAXV><<<nb, HDG_DOT_BLOCK, 0, stream>>>(g.Nc, p, d_ones_ptr, 1, d_part, mask_for(KC));
     k_reduce_parts<<<1, 256, 0, stream>>>(nb, 1, d_part, d_res);
+    comm->allreduce_sum(d_res, 1, stream);
     k_shift_p<<<vec_blocks(g.Nc), 256, 0, stream>>>(g.Nc, p, d_res, c0 / vol, c0);
     if (l)
       k_shift_l<<<corner_grid(), bs(), 0, stream>>>(g, NL, l, d_res, c0 / vol, std::sqrt(dt.elen[0]),
@@ -470,7 +533,7 @@ struct Engine {
       adv_apply(x, qstar, t, gamma);       // t = A x
       axpby(NQ, 1.0, b, -1.0, t);          // t = b - A x
       tent_precond(didx, t, w);
-      double beta = std::sqrt(dot(NQ, w, w));
+      double beta = std::sqrt(dot(NQ, w, w, KC));
       if (beta0 < 0) beta0 = beta;
       if (!(beta == beta)) throw NotConverged{"GMRES: NaN residual"};
       if (beta <= rtol * beta0 || beta == 0.0) return its;
@@ -488,7 +551,7 @@ struct Engine {
           // pointer list = V_0..V_j followed by w: gather through a small staging array
           std::vector<const double*> ptrs(gm_V.begin(), gm_V.begin() + j + 1);
           ptrs.push_back(w);
-          multidot(NQ, w, ptrs, h.data());
+          multidot(NQ, w, ptrs, h.data(), KC);
         }
         double ww = h[j + 1], s2 = 0.0;
         for (int l = 0; l <= j; l++) s2 += h[l] * h[l];
@@ -502,7 +565,7 @@ struct Engine {
         } else {
           // severe cancellation: orthogonalise explicitly and measure the norm (safe path)
           k_gs_update<MAXV><<<nvb, 256, 0, stream>>>(NQ, w, d_gmV, hc, j + 1, 1.0, gm_V[j + 1]);
-          hn = std::sqrt(dot(NQ, gm_V[j + 1], gm_V[j + 1]));
+          hn = std::sqrt(dot(NQ, gm_V[j + 1], gm_V[j + 1], KC));
           if (hn > 0) axpby(NQ, 0.0, w, 1.0 / hn, gm_V[j + 1]);
         }
         for (int l = 0; l <= j; l++) H[(size_t)l * m + j] = h[l];
@@ -561,7 +624,7 @@ struct Engine {
   // ------------------------------------------------------------------ trace solver
   void project_const(double* x) {
     // x <- x - n (n.x)/(n.n), n = trace coefficients of the constant 1 (null space, hdg_imex.py:480-489)
-    double nn = dot(NLv, tr_one, tr_one), nx_ = dot(NLv, tr_one, x);
+    double nn = dot(NLv, tr_one, tr_one, KL), nx_ = dot(NLv, tr_one, x, KL);
     axpby(NLv, -nx_ / nn, tr_one, 1.0, x);
   }
   void cheb_smooth(const double* b, double* x, bool zero_init, int its) {
@@ -614,10 +677,20 @@ struct Engine {
     }
     cheb_smooth(r, z, true, 2);
     trace_apply(z, r, 1.0, -1.0, wL2);
-    dim3 grid((g.nx + 1 + 63) / 64, g.ny + 1);
-    k_trace_to_p1<<<grid, 64, 0, stream>>>(g, NL, wL2, mg_b[0], dt.elen[0], dt.elen[2], dt.elen[1]);
+    halo_L(wL2);
+    k_trace_to_p1<<<corner_grid(), bs(), 0, stream>>>(g, NL, wL2, mg_b[0], dt.elen[0], dt.elen[2], dt.elen[1]);
+    if (comm->size > 1) {
+      // every rank contributes its (ny+1) vertex rows; owners' rows are copied into the global vector
+      const long blk = (long)(g.ny + 1) * (g.nx + 1);
+      comm->allgather(mg_b[0] + (long)g.joff * (g.nx + 1), mg_gather, (size_t)blk, stream);
+      for (int r = 0; r < comm->size; r++) {
+        const long rows = g.ny + (r == comm->size - 1 ? 1 : 0);
+        HIPCHECK(hipMemcpyAsync(mg_b[0] + (long)r * g.ny * (g.nx + 1), mg_gather + (long)r * blk,
+                                sizeof(double) * rows * (g.nx + 1), hipMemcpyDeviceToDevice, stream));
+      }
+    }
     vcycle(0);
-    k_p1_to_trace<<<grid, 64, 0, stream>>>(g, NL, mg_x[0], z, 1.0, dt.elen[0], dt.elen[2], dt.elen[1]);
+    k_p1_to_trace<<<corner_grid(), bs(), 0, stream>>>(g, NL, mg_x[0], z, 1.0, dt.elen[0], dt.elen[2], dt.elen[1]);
     cheb_smooth(r, z, false, 2);
   }
   void setup_trace_solver() {
@@ -631,6 +704,7 @@ struct Engine {
     }
     // multigrid hierarchy on the vertex grid
     if (cfg.trace_precond == 1) {
+      if (comm->size > 1) mg_gather = dalloc((long)comm->size * (g.ny + 1) * (g.nx + 1));
       int n = g.nx;
       while (true) {
         mg_n.push_back(n);
@@ -657,12 +731,12 @@ struct Engine {
     l_to_modal(hL_dev, cg_p);
     double lam = 1.0;
     for (int it = 0; it < 20; it++) {
-      double nrm = std::sqrt(dot(NLv, cg_p, cg_p));
+      double nrm = std::sqrt(dot(NLv, cg_p, cg_p, KL));
       axpby(NLv, 0.0, cg_p, 1.0 / nrm, cg_p);
       trace_apply(cg_p, nullptr, 0.0, 1.0, cg_Ap);
       zero(cg_z, NLv);
       trace_cheb(cg_Ap, ch_d, cg_z, 0.0, 1.0);
-      lam = std::sqrt(dot(NLv, cg_z, cg_z));
+      lam = std::sqrt(dot(NLv, cg_z, cg_z, KL));
       copy(cg_p, cg_z, NLv);
     }
     psets[idx].lmax = 1.1 * lam;
@@ -698,7 +772,7 @@ struct Engine {
     trace_precond(cg_r, cg_z);
     project_const(cg_z);
     double d2[2];
-    multidot(NLv, cg_z, {cg_r, cg_z}, d2);
+    multidot(NLv, cg_z, {cg_r, cg_z}, d2, KL);
     double rz = d2[0], norm0 = std::sqrt(d2[1]);
     if (!(norm0 == norm0)) throw NotConverged{"trace CG: NaN residual"};
     if (norm0 == 0.0) return 0;
@@ -706,14 +780,14 @@ struct Engine {
     int its = 0;
     while (true) {
       trace_apply(cg_p, nullptr, 0.0, 1.0, cg_Ap);
-      double pAp = dot(NLv, cg_p, cg_Ap);
+      double pAp = dot(NLv, cg_p, cg_Ap, KL);
       if (!(pAp > 0)) throw NotConverged{"trace CG: breakdown (p.Ap <= 0)"};
       double alpha = rz / pAp;
       axpby(NLv, alpha, cg_p, 1.0, x);
       axpby(NLv, -alpha, cg_Ap, 1.0, cg_r);
       trace_precond(cg_r, cg_z);
       project_const(cg_z);
-      multidot(NLv, cg_z, {cg_r, cg_z}, d2);
+      multidot(NLv, cg_z, {cg_r, cg_z}, d2, KL);
       its++;
       double nrm = std::sqrt(d2[1]);
       if (nrm <= rtol * norm0) return its;
@@ -741,7 +815,7 @@ struct Engine {
   std::vector<V3> fg_V, fg_Z;
   V3 fg_r{nullptr, nullptr, nullptr}, fg_w{nullptr, nullptr, nullptr}, fg_b{nullptr, nullptr, nullptr};
   V3 alloc3() { return V3{dalloc(NQ), dalloc(NPv), dalloc(NLv)}; }
-  double dot3(const V3& a, const V3& b) { return dot(NQ, a.u, b.u) + dot(NPv, a.p, b.p) + dot(NLv, a.l, b.l); }
+  double dot3(const V3& a, const V3& b) { return dot(NQ, a.u, b.u, KC) + dot(NPv, a.p, b.p, KC) + dot(NLv, a.l, b.l, KL); }
   void axpby3(double a, const V3& x, double b, V3& y) { axpby(NQ, a, x.u, b, y.u); axpby(NPv, a, x.p, b, y.p); axpby(NLv, a, x.l, b, y.l); }
   void copy3(V3& d, const V3& s_) { copy(d.u, s_.u, NQ); copy(d.p, s_.p, NPv); copy(d.l, s_.l, NLv); }
   void mono_apply(const V3& x, const double* qstar, double gamma, V3& out) {
@@ -966,12 +1040,12 @@ struct Engine {
   // ------------------------------------------------------------------ host <-> device fields
   long n_edges() const { return (long)g.nx * (g.ny + 1) + (long)(g.nx + 1) * g.ny + (long)g.nx * g.ny; }
   void put_Q(const double* host, double* modal) {
-    HIPCHECK(hipMemcpyAsync(hQ_dev, host, sizeof(double) * NQ, hipMemcpyHostToDevice, stream));
+    HIPCHECK(hipMemcpyAsync(hQ_dev, host, sizeof(double) * NQb, hipMemcpyHostToDevice, stream));
     q_to_modal(hQ_dev, modal);
     HIPCHECK(hipStreamSynchronize(stream));
   }
   void put_P(const double* host, double* modal) {
-    HIPCHECK(hipMemcpyAsync(hP_dev, host, sizeof(double) * NPv, hipMemcpyHostToDevice, stream));
+    HIPCHECK(hipMemcpyAsync(hP_dev, host, sizeof(double) * NPb, hipMemcpyHostToDevice, stream));
     p_to_modal(hP_dev, modal);
     HIPCHECK(hipStreamSynchronize(stream));
   }
@@ -982,12 +1056,12 @@ struct Engine {
   }
   void get_Q(const double* modal, double* host) {
     q_to_nodal(modal, hQ_dev);
-    HIPCHECK(hipMemcpyAsync(host, hQ_dev, sizeof(double) * NQ, hipMemcpyDeviceToHost, stream));
+    HIPCHECK(hipMemcpyAsync(host, hQ_dev, sizeof(double) * NQb, hipMemcpyDeviceToHost, stream));
     HIPCHECK(hipStreamSynchronize(stream));
   }
   void get_P(const double* modal, double* host) {
     p_to_nodal(modal, hP_dev);
-    HIPCHECK(hipMemcpyAsync(host, hP_dev, sizeof(double) * NPv, hipMemcpyDeviceToHost, stream));
+    HIPCHECK(hipMemcpyAsync(host, hP_dev, sizeof(double) * NPb, hipMemcpyDeviceToHost, stream));
     HIPCHECK(hipStreamSynchronize(stream));
   }
   void get_L(double* modal, double* host) {
@@ -1009,7 +1083,7 @@ struct Engine {
         for (int i = 0; i < g.nx; i++)
           for (int sh = 0; sh < 2; sh++) {
             const long c = 2 * ((long)j * g.nx + i) + sh;
-            const double x0 = (sh == 0 ? i : i + 1) * g.h, y0 = (sh == 0 ? j : j + 1) * g.h;
+            const double x0 = (sh == 0 ? i : i + 1) * g.h, y0 = (g.joff + (sh == 0 ? j : j + 1)) * g.h;
             const double sg = sh == 0 ? 1.0 : -1.0;
             for (long n = 0; n < nn; n++) {
               out[(c * nn + n) * 2 + 0] = x0 + sg * g.h * (double)xi[n];
@@ -1069,20 +1143,47 @@ static std::string g_create_error;
     return HDG_OK;                                                            \
   } catch (const hdg::HipError& e) { (h)->err = e.msg; return HDG_ERR_HIP;    \
   } catch (const hdg::NotConverged& e) { (h)->err = e.msg; return HDG_ERR_NOT_CONVERGED; \
+  } catch (const hdg::CommError& e) { (h)->err = e.msg; return HDG_ERR_COMM;       \
   } catch (const std::string& e) { (h)->err = e; return HDG_ERR_ARG;          \
   } catch (const std::exception& e) { (h)->err = e.what(); return HDG_ERR_ARG; \
   } catch (...) { (h)->err = "unknown error"; return HDG_ERR_ARG; }
 
 extern "C" {
 
-int hdg_create(const hdg_config* cfg, hdg_handle** out) {
-  if (!cfg || !out) return HDG_ERR_ARG;
+static int create_impl(const hdg_config* cfg, int rank, int nranks, int backend, const char* token, hdg_handle** out);
+int hdg_create(const hdg_config* cfg, hdg_handle** out) { return create_impl(cfg, 0, 1, 0, nullptr, out); }
+int hdg_create_distributed(const hdg_config* cfg, int rank, int nranks, int backend, const char* token, hdg_handle** out) {
+  return create_impl(cfg, rank, nranks, backend, token, out);
+}
+int hdg_rccl_unique_id(char* out128) {
+  if (!out128) return HDG_ERR_ARG;
+  ncclUniqueId id;
+  if (ncclGetUniqueId(&id) != ncclSuccess) return HDG_ERR_HIP;
+  std::memcpy(out128, &id, sizeof(id) < 128 ? sizeof(id) : 128);
+  return HDG_OK;
+}
+static int create_impl(const hdg_config* cfg, int rank, int nranks, int backend, const char* token, hdg_handle** out) {
+  if (!cfg || !out || nranks < 1 || rank < 0 || rank >= nranks) return HDG_ERR_ARG;
   *out = nullptr;
   try {
-    hdg::Engine* e = new hdg::Engine(*cfg);
+    if (hipSetDevice(cfg->device) != hipSuccess) { g_create_error = "hipSetDevice failed (no GPU?)"; return HDG_ERR_HIP; }
+    hdg::Comm* comm = nullptr;
+    if (nranks == 1) comm = new hdg::Comm();
+    else if (backend == HDG_COMM_RCCL) { if (!token) return HDG_ERR_ARG; comm = new hdg::CommRccl(rank, nranks, token); }
+    else if (backend == HDG_COMM_SHM) {
+      if (!token) return HDG_ERR_ARG;
+      const int k = cfg->degree;
+      const size_t nu = (size_t)(k + 2) * (k + 3) / 2;
+      const size_t P = ((size_t)cfg->nx + 1 + 15) / 16 * 16;
+      const size_t cap_halo = std::max<size_t>(2 * nu * 2 * cfg->nx, 3 * (size_t)(k + 1) * P);
+      const size_t cap_gather = ((size_t)cfg->ny / nranks + 1) * ((size_t)cfg->nx + 1);
+      comm = new hdg::CommShm(rank, nranks, token, cap_halo, cap_gather);
+    } else return HDG_ERR_ARG;
+    hdg::Engine* e = new hdg::Engine(*cfg, comm);
     *out = new hdg_handle{e, ""};
     return HDG_OK;
   } catch (const hdg::HipError& e) { g_create_error = e.msg; return HDG_ERR_HIP;
+  } catch (const hdg::CommError& e) { g_create_error = e.msg; return HDG_ERR_COMM;
   } catch (const std::string& e) { g_create_error = e; return HDG_ERR_ARG;
   } catch (const std::runtime_error& e) { g_create_error = e.what(); return HDG_ERR_SINGULAR;
   } catch (const std::exception& e) { g_create_error = e.what(); return HDG_ERR_ARG;
@@ -1099,7 +1200,7 @@ const char* hdg_last_error(const hdg_handle* h) { return h ? h->err.c_str() : g_
 int hdg_get_sizes(const hdg_handle* h, long* n_cells, long* n_edges, int* n_u, int* n_p, int* n_l) {
   if (!h || !h->eng) return HDG_ERR_ARG;
   const hdg::Engine& E = *h->eng;
-  if (n_cells) *n_cells = E.g.Nc;
+  if (n_cells) *n_cells = 2L * E.g.nx * E.g.ny;
   if (n_edges) *n_edges = E.n_edges();
   if (n_u) *n_u = E.NU;
   if (n_p) *n_p = E.NP;
@@ -1277,15 +1378,15 @@ int hdg_node_coordinates(hdg_handle* h, double* xq, double* xp) {
 }
 int hdg_l2_norms(hdg_handle* h, const double* Q, const double* p, double* norm_Q, double* norm_p) {
   HDG_API_BEGIN(h)
-  if (Q && norm_Q) { E.put_Q(Q, E.wQ1); *norm_Q = std::sqrt(E.dot(E.NQ, E.wQ1, E.wQ1)); }
-  if (p && norm_p) { E.put_P(p, E.wP1); *norm_p = std::sqrt(E.dot(E.NPv, E.wP1, E.wP1)); }
+  if (Q && norm_Q) { E.put_Q(Q, E.wQ1); *norm_Q = std::sqrt(E.dot(E.NQ, E.wQ1, E.wQ1, hdg::Engine::KC)); }
+  if (p && norm_p) { E.put_P(p, E.wP1); *norm_p = std::sqrt(E.dot(E.NPv, E.wP1, E.wP1, hdg::Engine::KC)); }
   HDG_API_END(h)
 }
 int hdg_integrate_pressure(hdg_handle* h, const double* p, double* integral) {
   HDG_API_BEGIN(h)
   if (!p || !integral) throw std::string("null argument");
   E.put_P(p, E.wP1);
-  *integral = E.g.h / std::sqrt(2.0) * E.dot(E.g.Nc, E.wP1, E.ones_c);
+  *integral = E.g.h / std::sqrt(2.0) * E.dot(E.g.Nc, E.wP1, E.ones_c, hdg::Engine::KC);
   HDG_API_END(h)
 }
 int hdg_time_kernel(hdg_handle* h, int kernel, int reps, double* ms_per_launch) {

@@ -18,9 +18,17 @@
 namespace hdg {
 
 struct Geo {
+  // Strip partition: a rank owns the cell rows joff .. joff+ny-1 of the global
+  // nx x nyg mesh.  Every array carries one GHOST row below (j = -1) and one above (j = ny):
+  //   cell index   c = (s*(ny+2) + (j+1))*nx + i          j in [-1, ny]
+  //   trace offset o = (j+1)*P + i                         corner rows j in [-1, ny]
+  // A rank computes the corner rows 0 .. nyc-1 (nyc = ny, or ny+1 on the topmost rank which also
+  // owns the edges on the top boundary); row ny of the other ranks is a ghost copy of the upper
+  // neighbour's row 0.  With one rank the ghost rows exist but are never referenced.
   int nx, ny, P;
-  long G;   // (ny+1)*P : one trace plane
-  long Nc;  // 2*nx*ny
+  int nyg, joff, nyc;
+  long G;   // (ny+2)*P : one trace plane
+  long Nc;  // 2*nx*(ny+2): stride between dof planes of a cell vector
   double h;
   // XCD-aware block mapping (1-D grids): workgroups are dealt round-robin over the 8 XCDs, so
   // blockIdx % 8 labels the XCD.  Each XCD owns a contiguous band of mesh rows and walks it row by
@@ -61,30 +69,34 @@ struct DevTables {
   const int i = (rem_ - s * g.nbx) * blockDim.x + threadIdx.x;     \
   const int j = xcd_ * g.rows_xcd + jj_;                           \
   if (jj_ >= g.rows_xcd || j >= g.ny || i >= g.nx) return;         \
-  const long c = ((long)s * g.ny + j) * g.nx + i;
+  const long c = ((long)s * (g.ny + 2) + (j + 1)) * g.nx + i;
 
 __device__ __forceinline__ bool nbr(int s, int e, int i, int j, const Geo& g, long& cn) {
   int in, jn;
   bool ok;
   if (s == 0) {
-    if (e == 0) { in = i; jn = j - 1; ok = j > 0; }
+    if (e == 0) { in = i; jn = j - 1; ok = (g.joff + j) > 0; }
     else if (e == 1) { in = i; jn = j; ok = true; }
     else { in = i - 1; jn = j; ok = i > 0; }
   } else {
-    if (e == 0) { in = i; jn = j + 1; ok = j < g.ny - 1; }
+    if (e == 0) { in = i; jn = j + 1; ok = (g.joff + j) < g.nyg - 1; }
     else if (e == 1) { in = i; jn = j; ok = true; }
     else { in = i + 1; jn = j; ok = i < g.nx - 1; }
   }
-  cn = ((long)(1 - s) * g.ny + jn) * g.nx + in;
+  cn = ((long)(1 - s) * (g.ny + 2) + (jn + 1)) * g.nx + in;
   return ok;
 }
 
 // offset (within a trace plane) and type of local edge e of cell (s,i,j)
 __device__ __forceinline__ long edge_off(int s, int e, int i, int j, const Geo& g, int& t) {
-  if (e == 0) { t = 0; return (long)(j + s) * g.P + i; }
-  if (e == 1) { t = 2; return (long)j * g.P + i; }
+  if (e == 0) { t = 0; return (long)(j + s + 1) * g.P + i; }
+  if (e == 1) { t = 2; return (long)(j + 1) * g.P + i; }
   t = 1;
-  return (long)j * g.P + i + s;
+  return (long)(j + 1) * g.P + i + s;
+}
+
+__device__ __forceinline__ long cidx(const Geo& g, int s, int j, int i) {
+  return ((long)s * (g.ny + 2) + (j + 1)) * g.nx + i;
 }
 
 template <int N>
@@ -379,9 +391,11 @@ __global__ __launch_bounds__(128) void k_weak_div(Geo g, DevTables T, const doub
   const int jj_ = q_ / g.nbxc;                                     \
   const int i = (q_ - jj_ * g.nbxc) * blockDim.x + threadIdx.x;    \
   const int j = xcd_ * g.rows_xcdc + jj_;                          \
-  if (jj_ >= g.rows_xcdc || j > g.ny || i > g.nx) return;          \
-  const long o = (long)j * g.P + i;                                \
-  const bool in_x = i < g.nx, in_y = j < g.ny;
+  if (jj_ >= g.rows_xcdc || j >= g.nyc || i > g.nx) return;        \
+  const long o = (long)(j + 1) * g.P + i;                          \
+  const bool in_x = i < g.nx, in_y = j < g.ny;                     \
+  const bool below = (g.joff + j) > 0;                             \
+  (void)below;
 
 template <int NL>
 __device__ __forceinline__ void load_tr(const double* __restrict__ l, const Geo& g, int t, long off, double* v) {
@@ -418,7 +432,7 @@ __global__ __launch_bounds__(128) void k_trace_apply(Geo g, DevTables T, const d
     load_tr<NL>(lam, g, 1, o + 1, u + 2 * NL);
     mv_acc_ld<NL, NT>(SU + 1 * NL * NT, NT, u, yD, -1.0);
   }
-  if (in_x && j > 0) {  // U(i,j-1): edges (H(i,j), D(i,j-1), V(i+1,j-1)), row block e0 -> H
+  if (in_x && below) {  // U(i,j-1): edges (H(i,j), D(i,j-1), V(i+1,j-1)), row block e0 -> H
     double u[NT];
 #pragma unroll
     for (int m = 0; m < NL; m++) u[m] = own[m];
@@ -456,7 +470,7 @@ __global__ __launch_bounds__(128) void k_trace_cheb(Geo g, DevTables T, const do
   for (int t = 0; t < 3; t++) {
     bool valid;
     int var;
-    if (t == 0) { valid = in_x; var = (j == 0) ? 1 : (j == g.ny ? 2 : 0); }
+    if (t == 0) { valid = in_x; var = (g.joff + j == 0) ? 1 : (g.joff + j == g.nyg ? 2 : 0); }
     else if (t == 1) { valid = in_y; var = (i == 0) ? 1 : (i == g.nx ? 2 : 0); }
     else { valid = in_x && in_y; var = 0; }
     if (!valid) continue;
@@ -503,16 +517,15 @@ __global__ __launch_bounds__(128) void k_condense(Geo g, DevTables T, const doub
   double yH[NL], yV[NL], yD[NL];
 #pragma unroll
   for (int m = 0; m < NL; m++) yH[m] = yV[m] = yD[m] = 0.0;
-  const long nxy = (long)g.nx * g.ny;
   if (in_x && in_y) {
-    const long cL = (long)j * g.nx + i, cU = nxy + cL;
+    const long cL = cidx(g, 0, j, i), cU = cidx(g, 1, j, i);
     y_rows<K, HASW, HASP>(T.Y[0], 0, rw, rp, g.Nc, cL, yH);
     y_rows<K, HASW, HASP>(T.Y[0], 1, rw, rp, g.Nc, cL, yD);
     y_rows<K, HASW, HASP>(T.Y[0], 2, rw, rp, g.Nc, cL, yV);
     y_rows<K, HASW, HASP>(T.Y[1], 1, rw, rp, g.Nc, cU, yD);
   }
-  if (in_x && j > 0) y_rows<K, HASW, HASP>(T.Y[1], 0, rw, rp, g.Nc, nxy + (long)(j - 1) * g.nx + i, yH);
-  if (in_y && i > 0) y_rows<K, HASW, HASP>(T.Y[1], 2, rw, rp, g.Nc, nxy + (long)j * g.nx + i - 1, yV);
+  if (in_x && below) y_rows<K, HASW, HASP>(T.Y[1], 0, rw, rp, g.Nc, cidx(g, 1, j - 1, i), yH);
+  if (in_y && i > 0) y_rows<K, HASW, HASP>(T.Y[1], 2, rw, rp, g.Nc, cidx(g, 1, j, i - 1), yV);
 #pragma unroll
   for (int m = 0; m < NL; m++) {
     const long iH = ((long)0 * NL + m) * g.G + o, iV = ((long)1 * NL + m) * g.G + o, iD = ((long)2 * NL + m) * g.G + o;
@@ -576,16 +589,15 @@ __global__ __launch_bounds__(128) void k_trace_recon(Geo g, DevTables T, const d
                                                       const double* __restrict__ p, double* __restrict__ out) {
   constexpr int NL = Dim<K>::NL;
   HDG_CORNER_PROLOGUE
-  const long nxy = (long)g.nx * g.ny;
   const double it = 1.0 / T.tau;
 #pragma unroll
   for (int t = 0; t < 3; t++) {
     const int e = (t == 0) ? 0 : (t == 1 ? 2 : 1);
     bool valid, hasL, hasU;
     long cL, cU;
-    if (t == 0) { valid = in_x; hasL = in_y; hasU = j > 0; cL = (long)j * g.nx + i; cU = nxy + (long)(j - 1) * g.nx + i; }
-    else if (t == 1) { valid = in_y; hasL = in_x; hasU = i > 0; cL = (long)j * g.nx + i; cU = nxy + (long)j * g.nx + i - 1; }
-    else { valid = in_x && in_y; hasL = hasU = true; cL = (long)j * g.nx + i; cU = nxy + cL; }
+    if (t == 0) { valid = in_x; hasL = in_y; hasU = below; cL = cidx(g, 0, j, i); cU = cidx(g, 1, j - 1, i); }
+    else if (t == 1) { valid = in_y; hasL = in_x; hasU = i > 0; cL = cidx(g, 0, j, i); cU = cidx(g, 1, j, i - 1); }
+    else { valid = in_x && in_y; hasL = hasU = true; cL = cidx(g, 0, j, i); cU = cidx(g, 1, j, i); }
     double acc[NL];
 #pragma unroll
     for (int m = 0; m < NL; m++) acc[m] = 0.0;
@@ -769,15 +781,14 @@ __global__ __launch_bounds__(128) void k_gamma_mu(Geo g, DevTables T, const doub
                                                    double* __restrict__ out) {
   constexpr int NL = Dim<K>::NL;
   HDG_CORNER_PROLOGUE
-  const long nxy = (long)g.nx * g.ny;
 #pragma unroll
   for (int t = 0; t < 3; t++) {
     const int e = (t == 0) ? 0 : (t == 1 ? 2 : 1);
     bool valid, hasL, hasU;
     long cL, cU;
-    if (t == 0) { valid = in_x; hasL = in_y; hasU = j > 0; cL = (long)j * g.nx + i; cU = nxy + (long)(j - 1) * g.nx + i; }
-    else if (t == 1) { valid = in_y; hasL = in_x; hasU = i > 0; cL = (long)j * g.nx + i; cU = nxy + (long)j * g.nx + i - 1; }
-    else { valid = in_x && in_y; hasL = hasU = true; cL = (long)j * g.nx + i; cU = nxy + cL; }
+    if (t == 0) { valid = in_x; hasL = in_y; hasU = below; cL = cidx(g, 0, j, i); cU = cidx(g, 1, j - 1, i); }
+    else if (t == 1) { valid = in_y; hasL = in_x; hasU = i > 0; cL = cidx(g, 0, j, i); cU = cidx(g, 1, j, i - 1); }
+    else { valid = in_x && in_y; hasL = hasU = true; cL = cidx(g, 0, j, i); cU = cidx(g, 1, j, i); }
     double acc[NL];
 #pragma unroll
     for (int m = 0; m < NL; m++) acc[m] = 0.0;
@@ -916,16 +927,25 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 // partial dots of w against nv vectors V[k] (k < nv <= MAXV): part[block*nv + k]; deterministic
 #define HDG_DOT_BLOCK 256
+// entries outside the rows [lo, hi] of the (ghosted) row structure are skipped: every dot product
+// counts each OWNED entry exactly once across ranks (w_ == 0: no mask)
+struct RowMask {
+  int w_, nrows, lo, hi;
+};
 template <int MAXV>
 __global__ __launch_bounds__(HDG_DOT_BLOCK) void k_multidot(long N, const double* __restrict__ w,
                                                              const double* const* __restrict__ V, int nv,
-                                                             double* __restrict__ part) {
+                                                             double* __restrict__ part, RowMask mk) {
   __shared__ double sm[HDG_DOT_BLOCK / 64][MAXV];
   double acc[MAXV];
 #pragma unroll
   for (int k = 0; k < MAXV; k++) acc[k] = 0.0;
   const long stride = (long)gridDim.x * blockDim.x;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < N; idx += stride) {
+    if (mk.w_ > 0) {
+      const int row = (int)((idx / mk.w_) % mk.nrows);
+      if (row < mk.lo || row > mk.hi) continue;
+    }
     const double wv = w[idx];
 #pragma unroll
     for (int k = 0; k < MAXV; k++)
@@ -1087,40 +1107,38 @@ __global__ void k_fill(long N, double* __restrict__ x, double v) {
 // without the reference's 1/2 on interior edges - a preconditioner detail)
 __global__ void k_p1_to_trace(Geo g, int NL, const double* __restrict__ xc, double* __restrict__ l, double accumulate,
                               double lH, double lV, double lD) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
-  if (i > g.nx) return;
-  const long o = (long)j * g.P + i;
+  HDG_CORNER_PROLOGUE
   const int st = g.nx + 1;
-  const bool in_x = i < g.nx, in_y = j < g.ny;
+  const long J = g.joff + j;  // global vertex row; xc is the global (replicated) vertex vector
   const double r3 = 0.57735026918962576451;
-  const double v00 = xc[j * st + i];
+  const double v00 = xc[J * st + i];
   if (in_x) {
-    const double vb = xc[j * st + i + 1], sl = sqrt(lH);
+    const double vb = xc[J * st + i + 1], sl = sqrt(lH);
     double* p0 = l + ((long)0 * NL) * g.G + o;
     double* p1 = l + ((long)0 * NL + 1) * g.G + o;
     *p0 = accumulate * (*p0) + sl * 0.5 * (v00 + vb);
     *p1 = accumulate * (*p1) + sl * r3 * 0.5 * (vb - v00);
   }
   if (in_y) {
-    const double vb = xc[(j + 1) * st + i], sl = sqrt(lV);
+    const double vb = xc[(J + 1) * st + i], sl = sqrt(lV);
     double* p0 = l + ((long)1 * NL) * g.G + o;
     double* p1 = l + ((long)1 * NL + 1) * g.G + o;
     *p0 = accumulate * (*p0) + sl * 0.5 * (v00 + vb);
     *p1 = accumulate * (*p1) + sl * r3 * 0.5 * (vb - v00);
   }
   if (in_x && in_y) {
-    const double va = xc[j * st + i + 1], vb = xc[(j + 1) * st + i], sl = sqrt(lD);
+    const double va = xc[J * st + i + 1], vb = xc[(J + 1) * st + i], sl = sqrt(lD);
     double* p0 = l + ((long)2 * NL) * g.G + o;
     double* p1 = l + ((long)2 * NL + 1) * g.G + o;
     *p0 = accumulate * (*p0) + sl * 0.5 * (va + vb);
     *p1 = accumulate * (*p1) + sl * r3 * 0.5 * (vb - va);
   }
 }
-// transpose: vertex gathers from its (up to six) incident edges
+// transpose: an OWNED vertex row gathers from its (up to six) incident edges (rows j and j-1; row -1
+// is the ghost row); writes the rank's rows of the global vertex vector
 __global__ void k_trace_to_p1(Geo g, int NL, const double* __restrict__ l, double* __restrict__ rc, double lH, double lV,
                               double lD) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
-  if (i > g.nx) return;
+  HDG_CORNER_PROLOGUE
   const int st = g.nx + 1;
   const double r3 = 0.57735026918962576451;
   const double* H0 = l + ((long)0 * NL) * g.G;
@@ -1129,16 +1147,43 @@ __global__ void k_trace_to_p1(Geo g, int NL, const double* __restrict__ l, doubl
   const double* V1 = l + ((long)1 * NL + 1) * g.G;
   const double* D0 = l + ((long)2 * NL) * g.G;
   const double* D1 = l + ((long)2 * NL + 1) * g.G;
-  const long o = (long)j * g.P + i;
   const double sH = 0.5 * sqrt(lH), sV = 0.5 * sqrt(lV), sD = 0.5 * sqrt(lD);
   double acc = 0.0;
   if (i < g.nx) acc += sH * (H0[o] - r3 * H1[o]);                              // H(i,j): a-end
   if (i > 0) acc += sH * (H0[o - 1] + r3 * H1[o - 1]);                         // H(i-1,j): b-end
-  if (j < g.ny) acc += sV * (V0[o] - r3 * V1[o]);                              // V(i,j): a-end
-  if (j > 0) acc += sV * (V0[o - g.P] + r3 * V1[o - g.P]);                     // V(i,j-1): b-end
-  if (i > 0 && j < g.ny) acc += sD * (D0[o - 1] - r3 * D1[o - 1]);             // D(i-1,j): a-end (x_{i},y_j)
-  if (i < g.nx && j > 0) acc += sD * (D0[o - g.P] + r3 * D1[o - g.P]);         // D(i,j-1): b-end (x_i,y_j)
-  rc[j * st + i] = acc;
+  if (in_y) acc += sV * (V0[o] - r3 * V1[o]);                                  // V(i,j): a-end
+  if (below) acc += sV * (V0[o - g.P] + r3 * V1[o - g.P]);                     // V(i,j-1): b-end
+  if (i > 0 && in_y) acc += sD * (D0[o - 1] - r3 * D1[o - 1]);                 // D(i-1,j): a-end (x_i,y_j)
+  if (i < g.nx && below) acc += sD * (D0[o - g.P] + r3 * D1[o - g.P]);         // D(i,j-1): b-end (x_i,y_j)
+  rc[(long)(g.joff + j) * st + i] = acc;
+}
+
+// ------------------------------------------------------------------------------------------
+// halo rows of the strip partition: pack the lowest / highest OWNED row of every plane into a
+// contiguous buffer, unpack received rows into the ghost rows.
+//   cell vectors:  planes = ndof * 2 shapes, row length nx,  row stride nx, plane stride (ny+2)*nx
+//   trace vectors: planes = 3 * NL,           row length P,   row stride P,  plane stride G
+// buf layout [plane][i]; `row` is the array row index (0 = ghost below, 1..ny owned, ny+1 ghost above)
+// ------------------------------------------------------------------------------------------
+__global__ void k_pack_rows(const double* __restrict__ v, long plane_stride, int row_len, int nplanes, int row,
+                            double* __restrict__ buf) {
+  const long n = (long)nplanes * row_len;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += stride) {
+    const long pl = idx / row_len;
+    const int i = (int)(idx - pl * row_len);
+    buf[idx] = v[pl * plane_stride + (long)row * row_len + i];
+  }
+}
+__global__ void k_unpack_rows(double* __restrict__ v, long plane_stride, int row_len, int nplanes, int row,
+                              const double* __restrict__ buf) {
+  const long n = (long)nplanes * row_len;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += stride) {
+    const long pl = idx / row_len;
+    const int i = (int)(idx - pl * row_len);
+    v[pl * plane_stride + (long)row * row_len + i] = buf[idx];
+  }
 }
 
 }  // namespace hdg

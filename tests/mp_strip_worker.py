@@ -1,0 +1,35 @@
+"""Worker of tests/test_gpu_multirank.py: one rank of a strip-partitioned HDG-IMEX run.
+
+usage: mp_strip_worker.py RANK NRANKS TOKEN K NX NSTEPS OUTFILE [unsplit]
+"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    rank, nranks, token, k, nx, nsteps, out = (int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4]),
+                                               int(sys.argv[5]), int(sys.argv[6]), sys.argv[7])
+    unsplit = len(sys.argv) > 8 and sys.argv[8] == "unsplit"
+    from incompressibleeulerhdg_amd import _lib
+    from incompressibleeulerhdg_amd.mesh import UnitSquareMesh
+    from incompressibleeulerhdg_amd.model_problems import TaylorGreen
+    from incompressibleeulerhdg_amd.timesteppers import IncompressibleEulerHDGIMEXSSP2_332
+
+    dt = 0.25 / nx
+    ts = IncompressibleEulerHDGIMEXSSP2_332(UnitSquareMesh(nx, nx), k, dt, use_projection_method=not unsplit,
+                                            n_richardson=2, rank=rank, nranks=nranks, comm_backend="shm", comm_token=token)
+    mp = TaylorGreen(ts._V_Q, ts._V_p)
+    Q, p = ts.solve(*mp.initial_condition(), None, mp.f_rhs(), nsteps * dt, fused=True)
+    lam = ts._engine.get_field(_lib.HDG_STATE_CURRENT, Q=False, p=False)[2]
+    Qe, pe = mp.solution(nsteps * dt, ts._engine.integrate_pressure)
+    eq, ep = ts._engine.l2_norms(Q.dat.data - Qe.dat.data, p.dat.data - pe.dat.data)
+    sums, cnt = ts._engine.iteration_stats()
+    np.savez(out, Q=Q.dat.data, p=p.dat.data, lam=lam, eq=eq, ep=ep, its=sums / np.maximum(cnt, 1))
+
+
+if __name__ == "__main__":
+    main()

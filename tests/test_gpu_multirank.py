@@ -1,0 +1,95 @@
+"""Strip-partitioned engine: P ranks (separate processes sharing the one GPU of the test box, shared-
+memory transport) must reproduce the single-rank fields to Krylov tolerance (SURVEY.md section 8e,
+"correctness gate") and take the same iteration counts up to reduction order."""
+import os
+import subprocess
+import sys
+import uuid
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _run_ranks(nranks, k, nx, nsteps, tmp_path, extra=()):
+    token = "/hdg_test_" + uuid.uuid4().hex[:12]
+    procs, outs = [], []
+    for r in range(nranks):
+        out = str(tmp_path / f"rank{r}.npz")
+        outs.append(out)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "mp_strip_worker.py"), str(r), str(nranks), token,
+                                       str(k), str(nx), str(nsteps), out, *extra],
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = []
+    for pr in procs:
+        try:
+            o, _ = pr.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append(o.decode(errors="replace"))
+    for r, pr in enumerate(procs):
+        assert pr.returncode == 0, f"rank {r} failed:\n{logs[r][-3000:]}"
+    return [np.load(o) for o in outs]
+
+
+def _assemble(parts, k, nx):
+    """Concatenate the strips into the global boundary numbering of a single rank."""
+    P = len(parts)
+    nyl = nx // P
+    nu, npp, nl = (k + 2) * (k + 3) // 2, (k + 1) * (k + 2) // 2, k + 1
+    Q = np.concatenate([d["Q"] for d in parts])  # cells are row-major in j, both shapes adjacent: strips concatenate
+    p = np.concatenate([d["p"] for d in parts])
+    NH_l, NV_l, ND_l = nx * (nyl + 1), (nx + 1) * nyl, nx * nyl
+    H, V, D = [], [], []
+    for r, d in enumerate(parts):
+        lam = d["lam"].reshape(-1, nl)
+        h = lam[:NH_l].reshape(nyl + 1, nx, nl)
+        H.append(h if r == P - 1 else h[:-1])  # the top row of a lower rank duplicates the upper rank's bottom row
+        V.append(lam[NH_l:NH_l + NV_l])
+        D.append(lam[NH_l + NV_l:])
+    lam = np.concatenate([np.concatenate(H).reshape(-1, nl), np.concatenate(V), np.concatenate(D)]).ravel()
+    return Q, p, lam
+
+
+@pytest.mark.parametrize("nranks,k,nx", [(2, 1, 8), (2, 2, 8), (4, 1, 8), (3, 2, 6)])
+def test_strip_partition_matches_single_rank(hip_lib, tmp_path, nranks, k, nx):
+    from incompressibleeulerhdg_amd import _lib
+    from incompressibleeulerhdg_amd.mesh import UnitSquareMesh
+    from incompressibleeulerhdg_amd.model_problems import TaylorGreen
+    from incompressibleeulerhdg_amd.timesteppers import IncompressibleEulerHDGIMEXSSP2_332
+
+    nsteps = 2
+    parts = _run_ranks(nranks, k, nx, nsteps, tmp_path)
+    Q, p, lam = _assemble(parts, k, nx)
+    dt = 0.25 / nx
+    ts = IncompressibleEulerHDGIMEXSSP2_332(UnitSquareMesh(nx, nx), k, dt, use_projection_method=True, n_richardson=2)
+    mp = TaylorGreen(ts._V_Q, ts._V_p)
+    Q1, p1 = ts.solve(*mp.initial_condition(), None, mp.f_rhs(), nsteps * dt, fused=True)
+    lam1 = ts._engine.get_field(_lib.HDG_STATE_CURRENT, Q=False, p=False)[2]
+    rel = lambda a, b: np.max(np.abs(a - b)) / np.max(np.abs(b))
+    assert rel(Q, Q1.dat.data) < 2e-8 and rel(p, p1.dat.data) < 2e-8 and rel(lam, lam1) < 2e-8
+    # global reductions agree on every rank
+    for d in parts[1:]:
+        assert abs(float(d["eq"]) - float(parts[0]["eq"])) < 1e-13 and np.allclose(d["its"], parts[0]["its"])
+    s1, c1 = ts._engine.iteration_stats()
+    assert np.all(np.abs(parts[0]["its"] - s1 / np.maximum(c1, 1)) <= 1.0)
+
+
+def test_strip_partition_unsplit(hip_lib, tmp_path):
+    from incompressibleeulerhdg_amd.mesh import UnitSquareMesh
+    from incompressibleeulerhdg_amd.model_problems import TaylorGreen
+    from incompressibleeulerhdg_amd.timesteppers import IncompressibleEulerHDGIMEXSSP2_332
+
+    k, nx = 1, 8
+    parts = _run_ranks(2, k, nx, 1, tmp_path, extra=("unsplit",))
+    Q, p, lam = _assemble(parts, k, nx)
+    dt = 0.25 / nx
+    ts = IncompressibleEulerHDGIMEXSSP2_332(UnitSquareMesh(nx, nx), k, dt, use_projection_method=False)
+    mp = TaylorGreen(ts._V_Q, ts._V_p)
+    Q1, p1 = ts.solve(*mp.initial_condition(), None, mp.f_rhs(), dt, fused=True)
+    rel = lambda a, b: np.max(np.abs(a - b)) / np.max(np.abs(b))
+    assert rel(Q, Q1.dat.data) < 2e-8 and rel(p, p1.dat.data) < 2e-8
