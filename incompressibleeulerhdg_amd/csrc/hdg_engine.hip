@@ -106,6 +106,7 @@ struct Engine {
   // multigrid levels (vertex grids)
   std::vector<int> mg_n;
   std::vector<double*> mg_x, mg_b, mg_r;
+  hipGraphExec_t vcycle_graph = nullptr;  // the V-cycle is a fixed launch sequence on fixed buffers
   // stats
   double it_sum[4] = {0, 0, 0, 0};
   long it_cnt[4] = {0, 0, 0, 0};
@@ -184,6 +185,7 @@ struct Engine {
     HIPCHECK(hipStreamSynchronize(stream));
   }
   ~Engine() {
+    if (vcycle_graph) (void)hipGraphExecDestroy(vcycle_graph);
     for (void* p : allocs) (void)hipFree(p);
     if (stream) (void)hipStreamDestroy(stream);
     delete tab;
@@ -655,12 +657,14 @@ struct Engine {
     int n = mg_n[lev];
     long nv = (long)(n + 1) * (n + 1);
     zero(mg_x[lev], nv);
+    static const int nsw = std::getenv("HDG_MG_SWEEPS") ? std::atoi(std::getenv("HDG_MG_SWEEPS")) : 2;
+    static const int ncoarse = std::getenv("HDG_MG_COARSE") ? std::atoi(std::getenv("HDG_MG_COARSE")) : 6;
     if (lev == (int)mg_n.size() - 1) {
-      p1_smooth(lev, 20, false);
-      p1_smooth(lev, 20, true);
+      p1_smooth(lev, ncoarse, false);
+      p1_smooth(lev, ncoarse, true);
       return;
     }
-    p1_smooth(lev, 2, false);
+    p1_smooth(lev, nsw, false);
     dim3 grid((n + 1 + 63) / 64, n + 1);
     k_p1_residual<<<grid, 64, 0, stream>>>(n, mg_x[lev], mg_b[lev], mg_r[lev]);
     int nc = mg_n[lev + 1];
@@ -668,7 +672,22 @@ struct Engine {
     k_p1_restrict<<<gridc, 64, 0, stream>>>(nc, mg_r[lev], mg_b[lev + 1]);
     vcycle(lev + 1);
     k_p1_prolong_add<<<grid, 64, 0, stream>>>(nc, mg_x[lev + 1], mg_x[lev]);
-    p1_smooth(lev, 2, true);
+    p1_smooth(lev, nsw, true);
+  }
+  // The V-cycle is ~165 launches of 1-10 us kernels: launch-bound.  Capture it once into a hipGraph
+  // (fixed sequence, fixed buffers) and replay it; HDG_NO_GRAPH=1 keeps the eager path.
+  void run_vcycle() {
+    if (std::getenv("HDG_NO_GRAPH")) { vcycle(0); return; }
+    if (!vcycle_graph) {
+      hipGraph_t graph = nullptr;
+      HIPCHECK(hipStreamSynchronize(stream));
+      HIPCHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+      vcycle(0);
+      HIPCHECK(hipStreamEndCapture(stream, &graph));
+      HIPCHECK(hipGraphInstantiate(&vcycle_graph, graph, nullptr, nullptr, 0));
+      (void)hipGraphDestroy(graph);
+    }
+    HIPCHECK(hipGraphLaunch(vcycle_graph, stream));
   }
   // z = M r for the condensed system
   void trace_precond(const double* r, double* z) {
@@ -691,7 +710,7 @@ struct Engine {
                                 sizeof(double) * rows * (g.nx + 1), hipMemcpyDeviceToDevice, stream));
       }
     }
-    vcycle(0);
+    run_vcycle();
     k_p1_to_trace<<<corner_grid(), bs(), 0, stream>>>(g, NL, mg_x[0], z, 1.0, dt.elen[0], dt.elen[2], dt.elen[1]);
     cheb_smooth(r, z, false, 2);
   }
