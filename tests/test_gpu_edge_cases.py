@@ -1,0 +1,107 @@
+"""Edge cases and error behaviour of the C-ABI on the GPU."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SSP2 = dict(nstages=3, a_expl=[[0, 0, 0], [0.5, 0, 0], [0.5, 0.5, 0]], a_impl=[[0.25, 0, 0], [0, 0.25, 0], [1 / 3, 1 / 3, 1 / 3]],
+            b_expl=[1 / 3] * 3, b_impl=[1 / 3] * 3, c_expl=[0, 1, 0.5])
+
+
+def _rel(a, b):
+    return np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300)
+
+
+@pytest.mark.parametrize("k,nx", [(1, 1), (1, 2), (1, 3), (2, 5), (1, 7), (4, 2)])
+def test_small_and_odd_meshes_match_oracle(hip_lib, k, nx):
+    """nx not a power of two (single or no multigrid coarsening), down to one square."""
+    from incompressibleeulerhdg_amd.mesh import UnitSquareMesh
+    from incompressibleeulerhdg_amd.model_problems import TaylorGreen
+    from incompressibleeulerhdg_amd.timesteppers import IncompressibleEulerHDGIMEXSSP2_332
+    from oracle import hdg_oracle as orc
+
+    dt = 0.25 / nx
+    ts = IncompressibleEulerHDGIMEXSSP2_332(UnitSquareMesh(nx, nx), k, dt, use_projection_method=True)
+    mp = TaylorGreen(ts._V_Q, ts._V_p)
+    Q, p = ts.solve(*mp.initial_condition(), None, mp.f_rhs(), 2 * dt, fused=True)
+    d = orc.HDGDiscretisation(nx, k)
+    tg = orc.TaylorGreen(d)
+    oQ, op = orc.OracleHDGIMEX(d, dt, "imex_ssp2_332").solve(*tg.initial_condition(), tg.f_rhs, 2 * dt)
+    assert _rel(Q.dat.data, oQ) < 2e-8 and _rel(p.dat.data, op) < 2e-8
+
+
+def test_bad_arguments_return_error_codes(hip_lib):
+    from incompressibleeulerhdg_amd._lib import Engine, HDGError
+
+    for bad in (dict(degree=0), dict(degree=5), dict(nx=0), dict(dt=0.0), dict(ny=5)):
+        kw = dict(nx=4, degree=1, dt=0.1, **SSP2)
+        kw.update(bad)
+        with pytest.raises(HDGError) as ei:
+            Engine(**kw)
+        assert ei.value.code == -1, bad
+    e = Engine(nx=4, degree=1, dt=0.1, **SSP2)
+    for call in (lambda: e.tentative_solve(0), lambda: e.tentative_solve(3), lambda: e.pressure_solve(7),
+                 lambda: e.project_bdm(5, 0), lambda: e.get_field(999), lambda: e.set_forcing_scale(9, 1.0),
+                 lambda: e.stage_update(0)):
+        with pytest.raises(HDGError) as ei:
+            call()
+        assert ei.value.code == -1
+    with pytest.raises(ValueError):
+        e.set_state(np.zeros((3, 2)), np.zeros(5))  # wrong shapes are caught before crossing the ABI
+
+
+def test_krylov_failure_is_an_error_not_silent(hip_lib):
+    """Krylov max-it is an error code, never silent."""
+    from incompressibleeulerhdg_amd._lib import Engine, HDGError
+
+    e = Engine(nx=8, degree=1, dt=0.03, tent_maxit=2, **SSP2)
+    rng = np.random.default_rng(0)
+    e.set_state(rng.standard_normal(e.shape_Q), rng.standard_normal(e.shape_p))
+    e.reconstruct_trace()
+    for i in range(4):
+        e.set_forcing_scale(i, 0.0)
+    e.begin_step()
+    e.project_bdm(0, 0)
+    with pytest.raises(HDGError) as ei:
+        e.tentative_solve(1)
+    assert ei.value.code == -3
+    e2 = Engine(nx=8, degree=1, dt=0.03, trace_maxit=1, **SSP2)
+    e2.set_state(rng.standard_normal(e2.shape_Q), rng.standard_normal(e2.shape_p))
+    e2.reconstruct_trace()
+    for i in range(4):
+        e2.set_forcing_scale(i, 0.0)
+    e2.begin_step()
+    with pytest.raises(HDGError) as ei:
+        e2.pressure_solve(0)
+    assert ei.value.code == -3
+
+
+def test_zero_forcing_and_zero_state(hip_lib):
+    """kappa == 0 (zero forcing, SURVEY C-6) and an all-zero state are fixed points."""
+    from incompressibleeulerhdg_amd.mesh import UnitSquareMesh
+    from incompressibleeulerhdg_amd.model_problems import TaylorGreen
+    from incompressibleeulerhdg_amd.timesteppers import IncompressibleEulerHDGIMEXSSP2_332
+
+    nx, k = 6, 1
+    ts = IncompressibleEulerHDGIMEXSSP2_332(UnitSquareMesh(nx, nx), k, 0.02)
+    Q, p = ts.solve(lambda x, y: (0 * x, 0 * x), lambda x, y: 0 * x, None, 0, 0.04, fused=True)
+    assert np.max(np.abs(Q.dat.data)) == 0.0 and np.max(np.abs(p.dat.data)) == 0.0
+    mp = TaylorGreen(ts._V_Q, ts._V_p, "exponential", 0.0)
+    Q, p = ts.solve(*mp.initial_condition(), None, mp.f_rhs(), 0.04, fused=True)
+    Qe, _ = mp.solution(0.04)
+    assert ts._engine.l2_norms(Q.dat.data - Qe.dat.data)[0] < 5e-3  # stationary vortex preserved to discretisation error
+
+
+def test_reproducible_bitwise(hip_lib):
+    """Owner-computes gather + deterministic reductions: two runs give identical bits."""
+    from incompressibleeulerhdg_amd.mesh import UnitSquareMesh
+    from incompressibleeulerhdg_amd.model_problems import TaylorGreen
+    from incompressibleeulerhdg_amd.timesteppers import IncompressibleEulerHDGIMEXSSP2_332
+
+    out = []
+    for _ in range(2):
+        ts = IncompressibleEulerHDGIMEXSSP2_332(UnitSquareMesh(16, 16), 2, 0.25 / 16)
+        mp = TaylorGreen(ts._V_Q, ts._V_p)
+        Q, p = ts.solve(*mp.initial_condition(), None, mp.f_rhs(), 0.5 / 16, fused=True)
+        out.append((Q.dat.data.copy(), p.dat.data.copy()))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
