@@ -144,6 +144,15 @@ def main():
             **comm_kwargs(backend, rank, world, token))
 
     backend = args.comm if world > 1 else "none"
+    if world > 1 and backend == "rccl":
+        # rehearse the transport in a child process first: a failure or hang costs a timeout, not the run
+        from incompressibleeulerhdg_amd.distributed import probe_transport
+
+        ok_probe = probe_transport("rccl")
+        if int(reduce_scalar(1.0 if ok_probe else 0.0, dist.ReduceOp.MIN)) == 0:
+            if rank == 0:
+                print("[bench] RCCL transport probe failed; using the shared-memory transport", file=sys.stderr)
+            backend = "shm"
     try:
         ts = build(backend)
         ok = 1
