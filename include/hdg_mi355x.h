@@ -68,6 +68,7 @@ typedef struct hdg_config {
   int tent_maxit;
   int gmres_restart;     /* PETSc default 30 */
   int tent_precond;      /* 0 element block-Jacobi, 1 two-level (block-Jacobi + BDM-conforming correction) */
+  int tent_solver;       /* 0 restarted GMRES, 1 one GMRES cycle (Ritz bounds) + Chebyshev iteration, GMRES fallback */
   double trace_rtol;     /* 1e-12 (hdg_imex.py:137) */
   int trace_maxit;
   int trace_precond;     /* 0 edge block-Jacobi, 1 GTMG-like two-level (P1 coarse space + geometric MG) */

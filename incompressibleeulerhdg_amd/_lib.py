@@ -56,6 +56,7 @@ class hdg_config(C.Structure):
         ("tent_maxit", C.c_int),
         ("gmres_restart", C.c_int),
         ("tent_precond", C.c_int),
+        ("tent_solver", C.c_int),
         ("trace_rtol", C.c_double),
         ("trace_maxit", C.c_int),
         ("trace_precond", C.c_int),
@@ -192,6 +193,7 @@ class Engine:
         cfg.tent_maxit = int(kw.get("tent_maxit", 2000))
         cfg.gmres_restart = int(kw.get("gmres_restart", 8))
         cfg.tent_precond = int(kw.get("tent_precond", 1))
+        cfg.tent_solver = int(kw.get("tent_solver", 1))
         cfg.trace_rtol = float(kw.get("trace_rtol", 1e-12))
         cfg.trace_maxit = int(kw.get("trace_maxit", 10000))
         cfg.trace_precond = int(kw.get("trace_precond", 1))

@@ -18,6 +18,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <complex>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -309,10 +310,10 @@ struct Engine {
     halo_Q(in);
     HDG_DISPATCH(k_edge_lift<KK, true, false><<<cell_grid(), bs(), 0, stream>>>(g, dt, in, out, nullptr, nullptr, nullptr));
   }
-  void adv_apply(const double* x, const double* qstar, double* out, double gamma) {
+  void adv_apply(const double* x, const double* qstar, double* out, double gamma, const double* bsub = nullptr) {
     halo_Q(x);
     const double up = cfg.flux_upwind ? 1.0 : 0.0;
-    HDG_DISPATCH(k_adv_apply<KK><<<cell_grid(), bs(), 0, stream>>>(g, dt, x, qstar, out, gamma, up));
+    HDG_DISPATCH(k_adv_apply<KK><<<cell_grid(), bs(), 0, stream>>>(g, dt, x, qstar, out, gamma, up, bsub));
   }
   void blockdiag(const double* D0, const double* D1, const double* r, const double* zin, double cz, double* out) {
     HDG_DISPATCH(k_blockdiag<KK><<<cell_grid(), bs(), 0, stream>>>(g, D0, D1, r, zin, cz, out));
@@ -522,31 +523,38 @@ struct Engine {
   // solve (I - gamma F(Q*)) x = b with left-preconditioned GMRES(m); x holds the initial guess.
   // Convergence: ||M r|| <= rtol * ||M r0||  (PETSc default for the SNES-ksponly linear solve the
   // reference performs: relative to the residual at the warm start)
+  // ritz != nullptr: run ONE cycle of at most m_cycle iterations, return the eigenvalue real parts of
+  // its Hessenberg matrix (Ritz values of the preconditioned operator) and the initial / final
+  // preconditioned residual norms through *beta_first / *beta_last (beta_last is the Arnoldi estimate).
   int gmres(const double* qstar, double gamma, int didx, const double* b, double* x, double rtol = -1.0,
-            int maxit = -1, bool strict = true) {
+            int maxit = -1, bool strict = true, std::vector<double>* ritz = nullptr, int m_cycle = 0,
+            double* beta_first = nullptr, double* beta_last = nullptr, double beta0_given = -1.0) {
     const int m = std::min(std::max(1, cfg.gmres_restart), MAXV - 1);  // allocated basis / Hessenberg stride
     // adaptive cycle length: short cycles keep the Krylov-basis traffic low (the preconditioned operator
     // is benign: GMRES(4) needs 45.5 iterations where GMRES(30) needs 42.5 at C3); a cycle that reduces
     // the residual by less than 2x doubles the length, up to the configured restart
     int mcur = std::min(m, 4);
+    if (ritz) mcur = std::min(m, std::max(1, m_cycle));
     double beta_prev = -1.0;
+    std::vector<double> Hraw;
     if (rtol < 0) rtol = cfg.tent_rtol;
     if (maxit < 0) maxit = cfg.tent_maxit;
     int its = 0;
-    double beta0 = -1.0;
+    double beta0 = beta0_given;
     std::vector<double> H((size_t)(m + 1) * m, 0.0), cs(m), sn(m), gv(m + 1);
     double* w = wQ1;
     double* t = wQ2;
     const int nvb = vec_blocks(NQ);
     while (true) {
-      adv_apply(x, qstar, t, gamma);       // t = A x
-      axpby(NQ, 1.0, b, -1.0, t);          // t = b - A x
+      adv_apply(x, qstar, t, gamma, b);    // t = b - A x  (residual fused into the operator kernel)
       tent_precond(didx, t, w);
       double beta = std::sqrt(dot(NQ, w, w, KC));
       if (beta0 < 0) beta0 = beta;
+      if (beta_first) *beta_first = beta;
+      if (beta_last) *beta_last = beta;
       if (!(beta == beta)) throw NotConverged{"GMRES: NaN residual"};
       if (beta <= rtol * beta0 || beta == 0.0) return its;
-      if (beta_prev > 0 && beta > 0.5 * beta_prev) mcur = std::min(m, 2 * mcur);
+      if (!ritz && beta_prev > 0 && beta > 0.5 * beta_prev) mcur = std::min(m, 2 * mcur);
       beta_prev = beta;
       k_gs_update<MAXV><<<nvb, 256, 0, stream>>>(NQ, w, d_gmV, Coefs(), 0, 1.0 / beta, gm_V[0]);
       std::fill(gv.begin(), gv.end(), 0.0);
@@ -581,6 +589,11 @@ struct Engine {
         }
         for (int l = 0; l <= j; l++) H[(size_t)l * m + j] = h[l];
         H[(size_t)(j + 1) * m + j] = hn;
+        if (ritz) {
+          if (Hraw.empty()) Hraw.assign((size_t)m * m, 0.0);
+          for (int l = 0; l <= j; l++) Hraw[(size_t)l * m + j] = h[l];
+          if (j + 1 < m) Hraw[(size_t)(j + 1) * m + j] = hn;
+        }
         for (int l = 0; l < j; l++) {
           double a1 = H[(size_t)l * m + j], a2 = H[(size_t)(l + 1) * m + j];
           H[(size_t)l * m + j] = cs[l] * a1 + sn[l] * a2;
@@ -596,6 +609,7 @@ struct Engine {
         gv[j] = cs[j] * gv[j];
         its++;
         double res = std::fabs(gv[j + 1]);
+        if (beta_last) *beta_last = res;
         if (res <= rtol * beta0 || hn == 0.0) { j++; done = true; break; }
         if (its >= maxit) { j++; done = false; break; }
       }
@@ -608,11 +622,126 @@ struct Engine {
       }
       for (int l = 0; l < j; l++) yc.c[l] = y[l];
       k_basis_axpy<MAXV><<<nvb, 256, 0, stream>>>(NQ, x, d_gmV, yc, j);
+      if (ritz) {
+        // Ritz values: eigenvalues of the leading j x j block of the (unrotated) Hessenberg matrix
+        std::vector<double> Hs((size_t)j * j);
+        for (int a = 0; a < j; a++) for (int c = 0; c < j; c++) Hs[(size_t)a * j + c] = Hraw[(size_t)a * m + c];
+        *ritz = hessenberg_eig_real(Hs, j);
+        return its;
+      }
       if (done) return its;
       if (its >= maxit) {
         if (strict) throw NotConverged{"tentative-velocity GMRES reached max iterations"};
         return its;
       }
+    }
+  }
+
+  // real parts of the eigenvalues of a small upper Hessenberg matrix: shifted QR iteration in complex
+  // arithmetic with deflation (n <= 32, used for Ritz values only)
+  static std::vector<double> hessenberg_eig_real(const std::vector<double>& Hin, int n) {
+    typedef std::complex<double> cd;
+    std::vector<cd> H((size_t)n * n);
+    for (int i = 0; i < n * n; i++) H[i] = Hin[i];
+    std::vector<double> ev;
+    int hi = n - 1;
+    int guard = 0;
+    while (hi >= 0 && guard++ < 10000) {
+      if (hi == 0) { ev.push_back(H[0].real()); break; }
+      // deflate
+      double sub = std::abs(H[(size_t)hi * n + hi - 1]);
+      double diag = std::abs(H[(size_t)hi * n + hi]) + std::abs(H[(size_t)(hi - 1) * n + hi - 1]);
+      if (sub <= 1e-14 * (diag > 0 ? diag : 1.0)) { ev.push_back(H[(size_t)hi * n + hi].real()); hi--; continue; }
+      // Wilkinson shift from the trailing 2x2 block
+      cd a = H[(size_t)(hi - 1) * n + hi - 1], b = H[(size_t)(hi - 1) * n + hi], c = H[(size_t)hi * n + hi - 1], d = H[(size_t)hi * n + hi];
+      cd tr = a + d, det = a * d - b * c, disc = std::sqrt(tr * tr - 4.0 * det);
+      cd l1 = 0.5 * (tr + disc), l2 = 0.5 * (tr - disc);
+      cd mu = (std::abs(l1 - d) < std::abs(l2 - d)) ? l1 : l2;
+      if (guard % 11 == 10) mu += cd(0.37 * sub, 0.11 * sub);  // exceptional shift
+      // QR step on the active block 0..hi by Givens rotations
+      std::vector<cd> cs_(hi), sn_(hi);
+      for (int i = 0; i <= hi; i++) H[(size_t)i * n + i] -= mu;
+      for (int k = 0; k < hi; k++) {
+        cd x = H[(size_t)k * n + k], y = H[(size_t)(k + 1) * n + k];
+        double r = std::sqrt(std::norm(x) + std::norm(y));
+        cd cc = (r == 0) ? cd(1) : x / r, ss = (r == 0) ? cd(0) : y / r;
+        cs_[k] = cc; sn_[k] = ss;
+        for (int col = k; col <= hi; col++) {
+          cd u = H[(size_t)k * n + col], v = H[(size_t)(k + 1) * n + col];
+          H[(size_t)k * n + col] = std::conj(cc) * u + std::conj(ss) * v;
+          H[(size_t)(k + 1) * n + col] = -ss * u + cc * v;
+        }
+      }
+      for (int k = 0; k < hi; k++) {
+        int rmax = std::min(hi, k + 1);
+        for (int row = 0; row <= rmax; row++) {
+          cd u = H[(size_t)row * n + k], v = H[(size_t)row * n + k + 1];
+          H[(size_t)row * n + k] = u * cs_[k] + v * sn_[k];
+          H[(size_t)row * n + k + 1] = -u * std::conj(sn_[k]) + v * std::conj(cs_[k]);
+        }
+      }
+      for (int i = 0; i <= hi; i++) H[(size_t)i * n + i] += mu;
+    }
+    return ev;
+  }
+
+  // Tentative-velocity solver (default): one short GMRES cycle, then Chebyshev iteration.
+  // GMRES(4) needs as many iterations as GMRES(30) on this operator, i.e. the preconditioned iteration is
+  // essentially stationary; a Chebyshev iteration reaches the same rate with NO inner products and no
+  // Krylov basis (per iteration: operator + preconditioner + one fused update, one norm every 4th
+  // iteration).  Spectral bounds come from the Ritz values of the opening GMRES cycle of THIS solve
+  // (merged with the bounds seen so far for the stage), with safety factors; if the iteration stalls or
+  // grows, the solve is finished by GMRES.  Same stopping rule as GMRES: ||M r|| <= rtol ||M r_0||.
+  std::vector<double> ch_lmin, ch_lmax;
+  double* chd = nullptr;
+  int cheb_gmres(const double* qstar, double gamma, int didx, const double* b, double* x) {
+    const double rtol = cfg.tent_rtol;
+    if ((int)ch_lmin.size() < s + 1) { ch_lmin.assign(s + 1, -1.0); ch_lmax.assign(s + 1, -1.0); }
+    if (!chd) chd = dalloc(NQ);
+    std::vector<double> ritz;
+    double beta0 = 0.0, beta = 0.0;
+    int its = gmres(qstar, gamma, didx, b, x, rtol, cfg.tent_maxit, true, &ritz, 6, &beta0, &beta);
+    if (beta <= rtol * beta0 || beta0 == 0.0) return its;
+    double lo = 1e300, hi = -1e300;
+    for (double v : ritz) { lo = std::min(lo, v); hi = std::max(hi, v); }
+    if (!(lo > 0) || !(hi > lo)) return its + gmres(qstar, gamma, didx, b, x, rtol, cfg.tent_maxit, true, nullptr, 0, nullptr, nullptr, beta0);
+    // Ritz values lie inside the spectrum: widen; keep the widest interval seen for this stage
+    lo *= 0.8; hi *= 1.15;
+    if (ch_lmin[didx] > 0) { lo = std::min(lo, ch_lmin[didx]); hi = std::max(hi, ch_lmax[didx]); }
+    ch_lmin[didx] = lo; ch_lmax[didx] = hi;
+    const double theta = 0.5 * (hi + lo), delta = 0.5 * (hi - lo), sigma = theta / delta;
+    double rho = 1.0 / sigma;
+    double* t = wQ2;
+    double* z = wQ1;
+    const int nvb = vec_blocks(NQ);
+    // expected iterations for the remaining reduction (asymptotic Chebyshev rate), used as a stall guard
+    const double kap = hi / lo, rate = (std::sqrt(kap) - 1.0) / (std::sqrt(kap) + 1.0);
+    const int expected = (int)(std::log(std::max(rtol * beta0 / beta, 1e-300)) / std::log(rate)) + 8;
+    adv_apply(x, qstar, t, gamma, b);
+    tent_precond(didx, t, z);
+    k_cheb_update<<<nvb, 256, 0, stream>>>(NQ, chd, z, x, 0.0, 1.0 / theta);
+    int k = 1;
+    its++;
+    double last = beta;
+    while (true) {
+      adv_apply(x, qstar, t, gamma, b);
+      tent_precond(didx, t, z);
+      if (k % 4 == 0) {
+        double nz = std::sqrt(dot(NQ, z, z, KC));
+        if (!(nz == nz)) throw NotConverged{"Chebyshev: NaN residual"};
+        if (nz <= rtol * beta0) return its;
+        if (nz > 1e3 * last || k > 2 * expected + 16 || its >= cfg.tent_maxit) {
+          // bounds were wrong for this system: forget them and finish with GMRES
+          ch_lmin[didx] = ch_lmax[didx] = -1.0;
+          return its + gmres(qstar, gamma, didx, b, x, rtol, cfg.tent_maxit, true, nullptr, 0, nullptr, nullptr, beta0);
+        }
+        last = std::min(last, nz);
+      }
+      const double rn = 1.0 / (2.0 * sigma - rho);
+      k_cheb_update<<<nvb, 256, 0, stream>>>(NQ, chd, z, x, rn * rho, 2.0 * rn / delta);
+      rho = rn;
+      k++;
+      its++;
     }
   }
 
@@ -627,7 +756,8 @@ struct Engine {
     // rhs = r_i - (I - gamma F) Q_i + gamma g(w, p_i, lambda_i)      (hdg_imex.py:239-247)
     double* rhs = updU;  // _update.u is overwritten by the following pressure solve anyway
     pgrad(wQ3, 1.0, wQ4, -1.0, stP[i], stL[i], gamma, rhs);
-    int its = gmres(Qstar[i - 1], gamma, i, rhs, Qtent[i]);
+    int its = cfg.tent_solver == 0 ? gmres(Qstar[i - 1], gamma, i, rhs, Qtent[i])
+                                   : cheb_gmres(Qstar[i - 1], gamma, i, rhs, Qtent[i]);
     it_sum[0] += its; it_cnt[0]++;
     return its;
   }
@@ -1053,7 +1183,8 @@ struct Engine {
     // rhs lives in updU: wQ1..wQ4 are scratch of GMRES and its preconditioner
     lincomb(NQ, {{curQ, 1.0}, {bvec(0), dtt * bscale[0]}}, updU);  // (Q,w) + dt (f,w)
     zero(Qtent[0], NQ);
-    int it1 = gmres(Qstar[0], dtt, 0, updU, Qtent[0]);           // hdg_implicit.py:103-129
+    int it1 = cfg.tent_solver == 0 ? gmres(Qstar[0], dtt, 0, updU, Qtent[0])   // hdg_implicit.py:103-129
+                                   : cheb_gmres(Qstar[0], dtt, 0, updU, Qtent[0]);
     weak_div(Qtent[0], -1.0 / dtt, wP1, true);                   // hdg_implicit.py:145
     condense(nullptr, wP1, nullptr, wL1);
     zero(updL, NLv);

@@ -184,10 +184,11 @@ __global__ __launch_bounds__(128) void k_edge_lift(Geo g, DevTables T, const dou
 //   (x_K' := 0 on boundary edges; Q*.n = 0 there).  Quadrature: cell rule exact to 3k+2, edge rule
 //   ceil((3k+4)/2) Gauss points (the |Q*.n| integrand is not polynomial: SURVEY.md App. D.3).
 // ------------------------------------------------------------------------------------------
+//   Optional residual epilogue: with bsub != nullptr the kernel writes  bsub - (x - gamma F x).
 template <int K>
 __global__ __launch_bounds__(128) void k_adv_apply(Geo g, DevTables T, const double* __restrict__ xin,
                                                     const double* __restrict__ qstar, double* __restrict__ out,
-                                                    double gamma, double upwind) {
+                                                    double gamma, double upwind, const double* __restrict__ bsub) {
   constexpr int NU = Dim<K>::NU, N2 = 2 * NU;
   HDG_CELL_PROLOGUE
   double x[N2], qs[N2], F[N2];
@@ -267,8 +268,13 @@ __global__ __launch_bounds__(128) void k_adv_apply(Geo g, DevTables T, const dou
       }
     }
   }
+  if (bsub) {
 #pragma unroll
-  for (int n = 0; n < N2; n++) out[(long)n * g.Nc + c] = fma(-gamma, F[n], x[n]);
+    for (int n = 0; n < N2; n++) out[(long)n * g.Nc + c] = bsub[(long)n * g.Nc + c] - fma(-gamma, F[n], x[n]);
+  } else {
+#pragma unroll
+    for (int n = 0; n < N2; n++) out[(long)n * g.Nc + c] = fma(-gamma, F[n], x[n]);
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -991,6 +997,17 @@ __global__ void k_multiaxpy(long N, double* __restrict__ w, const double* const*
     for (int k = 0; k < MAXV; k++)
       if (k < nv) acc = fma(sign * hcoef[k], V[k][idx], acc);
     w[idx] = acc;
+  }
+}
+
+// Chebyshev step on velocity vectors:  d = c1*d + c2*z ;  x += d
+__global__ void k_cheb_update(long N, double* __restrict__ d, const double* __restrict__ z, double* __restrict__ x,
+                              double c1, double c2) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < N; idx += stride) {
+    const double dn = (c1 != 0.0) ? fma(c1, d[idx], c2 * z[idx]) : c2 * z[idx];
+    d[idx] = dn;
+    x[idx] += dn;
   }
 }
 
