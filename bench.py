@@ -188,32 +188,37 @@ def main():
             ("tentative", "pressure", "final_pressure", "pressure_reconstruction"), sums, cnt)}
         ntot = eng.n_total
         value = ntot * args.steps / elapsed / 1e6
-        # --- roofline of the dominant kernel (advection apply, K3): algorithmic bytes = 3 velocity
-        # vectors (x, Q*, y), 8 B per entry, duration from HIP events on the
-        # engine's stream
+        # --- roofline of the dominant kernel.  With the Chebyshev tentative solver the kernel with the
+        # largest share of the step (38 %, profiles/r01_e_*) is k_edge_lift<K,false,true>: BDM lift Pi +
+        # element block-Jacobi + Chebyshev update in one pass.  Algorithmic bytes per launch: it reads
+        # 4 velocity vectors (lift input, residual, direction d, iterate x) and writes 2 (d, x), 8 B per
+        # entry; duration from HIP events on the engine's stream.
         NQ = eng.n_cells * 2 * eng.n_u  # this rank's strip: kernel timings below are per-rank launches
-        ms_adv = eng.time_kernel(0, 20)
-        ms_tr = eng.time_kernel(1, 50)
-        ms_bdm = eng.time_kernel(2, 20)
-        ms_bs = eng.time_kernel(3, 20)
         NL = eng.n_edges * eng.n_l
         NP = eng.n_cells * eng.n_p
-        adv_bytes = 8.0 * 3 * NQ
+        ms_lift = eng.time_kernel(4, 20)
+        ms_adv = eng.time_kernel(0, 20)
+        ms_liftT = eng.time_kernel(5, 20)
+        ms_tr = eng.time_kernel(1, 50)
+        ms_bs = eng.time_kernel(3, 20)
+        lift_bytes = 8.0 * 6 * NQ
         traffic = None
-        try:  # HBM bytes per launch from the committed PMC passes (same workload only)
+        try:  # HBM bytes per launch from the committed PMC passes (same workload, single rank only)
             tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
             if tj["workload"] == {"nx": nx, "degree": k} and world == 1:
-                traffic = tj["kernels"]["k_adv_apply"]["hbm_bytes"]
+                traffic = tj["kernels"]["k_edge_lift<false,true>+cheb"]["hbm_bytes"]
         except Exception:
             traffic = None
-        roof = dict(bound="hbm", kernel="k_adv_apply", achieved=adv_bytes / (ms_adv * 1e-3) / 1e9, peak=HBM_PEAK_GBS,
-                    unit="GB/s", frac=adv_bytes / (ms_adv * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=traffic,
-                    algorithmic_bytes=adv_bytes,
-                    ms_per_launch=ms_adv,
+        gbs = lambda b, ms: b / (ms * 1e-3) / 1e9
+        roof = dict(bound="hbm", kernel="k_edge_lift<K,false,true> (BDM lift + block-Jacobi + Chebyshev step)",
+                    achieved=gbs(lift_bytes, ms_lift), peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=gbs(lift_bytes, ms_lift) / HBM_PEAK_GBS, traffic=traffic, algorithmic_bytes=lift_bytes,
+                    ms_per_launch=ms_lift,
                     other_kernels={
-                        "k_trace_apply": dict(ms=ms_tr, GBs=8.0 * 2 * NL / (ms_tr * 1e-3) / 1e9),
-                        "k_edge_lift(bdm)": dict(ms=ms_bdm, GBs=8.0 * 2 * NQ / (ms_bdm * 1e-3) / 1e9),
-                        "k_backsub": dict(ms=ms_bs, GBs=8.0 * (NL + 2 * NQ + 2 * NP) / (ms_bs * 1e-3) / 1e9),
+                        "k_adv_apply": dict(ms=ms_adv, GBs=gbs(8.0 * 3 * NQ, ms_adv)),
+                        "k_edge_lift<K,true,false>": dict(ms=ms_liftT, GBs=gbs(8.0 * 2 * NQ, ms_liftT)),
+                        "k_trace_apply": dict(ms=ms_tr, GBs=gbs(8.0 * 2 * NL, ms_tr)),
+                        "k_backsub": dict(ms=ms_bs, GBs=gbs(8.0 * (NL + 2 * NQ + 2 * NP), ms_bs)),
                     })
         line = {
             "metric": "million DOF-updates/sec (HDG-IMEX k=2, 1024^2 tri mesh)" if (nx, k) == (1024, 2)

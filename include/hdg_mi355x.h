@@ -167,7 +167,8 @@ int hdg_apply_trace_operator(hdg_handle* h, const double* lam, double* out);
 int hdg_apply_weak_divergence(hdg_handle* h, const double* Q, int broken, double* out_p);
 /* device-resident micro-benchmarks for bench.py: run `reps` launches of one kernel on the internal
  * stream, return the average milliseconds per launch measured with HIP events on that stream.
- * kernel: 0 advection apply, 1 trace apply, 2 BDM projection, 3 back-substitution */
+ * kernel: 0 advection apply, 1 trace apply, 2 BDM projection, 3 back-substitution,
+ *         4 BDM lift + block-Jacobi + Chebyshev step (fused), 5 transposed BDM lift */
 int hdg_time_kernel(hdg_handle* h, int kernel, int reps, double* ms_per_launch);
 
 #ifdef __cplusplus

@@ -299,16 +299,17 @@ struct Engine {
 
   void bdm(const double* in, double* out) {
     halo_Q(in);
-    HDG_DISPATCH(k_edge_lift<KK, false, false><<<cell_grid(), bs(), 0, stream>>>(g, dt, in, out, nullptr, nullptr, nullptr));
+    HDG_DISPATCH(k_edge_lift<KK, false, false><<<cell_grid(), bs(), 0, stream>>>(g, dt, in, out, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, 0.0));
   }
   // out = Pi(in) + Dinv r   (second half of the two-level preconditioner, block-Jacobi fused in)
-  void bdm_plus_bj(const double* in, double* out, const double* r, const double* D0, const double* D1) {
+  void bdm_plus_bj(const double* in, double* out, const double* r, const double* D0, const double* D1,
+                   double* chd_ = nullptr, double* chx_ = nullptr, double c1 = 0.0, double c2 = 0.0) {
     halo_Q(in);
-    HDG_DISPATCH(k_edge_lift<KK, false, true><<<cell_grid(), bs(), 0, stream>>>(g, dt, in, out, r, D0, D1));
+    HDG_DISPATCH(k_edge_lift<KK, false, true><<<cell_grid(), bs(), 0, stream>>>(g, dt, in, out, r, D0, D1, chd_, chx_, c1, c2));
   }
   void bdm_T(const double* in, double* out) {
     halo_Q(in);
-    HDG_DISPATCH(k_edge_lift<KK, true, false><<<cell_grid(), bs(), 0, stream>>>(g, dt, in, out, nullptr, nullptr, nullptr));
+    HDG_DISPATCH(k_edge_lift<KK, true, false><<<cell_grid(), bs(), 0, stream>>>(g, dt, in, out, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, 0.0));
   }
   void adv_apply(const double* x, const double* qstar, double* out, double gamma, const double* bsub = nullptr) {
     halo_Q(x);
@@ -520,6 +521,18 @@ struct Engine {
       bdm_plus_bj(wQ3, z, r, dinv0[didx], dinv1[didx]);
     }
   }
+  // z = M r fused with the Chebyshev step d = c1 d + c2 z, x += d (owned rows only: the ghost rows of x are
+  // refreshed by the next operator application); z is written to `zout` only when it is needed
+  void tent_precond_cheb(int didx, const double* r, double* zout, double* d_, double* x_, double c1, double c2) {
+    if (cfg.tent_precond == 0) {
+      blockdiag(dinv0[didx], dinv1[didx], r, nullptr, 0.0, wQ4);
+      if (zout) copy(zout, wQ4, NQ);
+      k_cheb_update<<<vec_blocks(NQ), 256, 0, stream>>>(NQ, d_, wQ4, x_, c1, c2);
+    } else {
+      bdm_T(r, wQ3);
+      bdm_plus_bj(wQ3, zout, r, dinv0[didx], dinv1[didx], d_, x_, c1, c2);
+    }
+  }
   // solve (I - gamma F(Q*)) x = b with left-preconditioned GMRES(m); x holds the initial guess.
   // Convergence: ||M r|| <= rtol * ||M r0||  (PETSc default for the SNES-ksponly linear solve the
   // reference performs: relative to the residual at the warm start)
@@ -693,22 +706,37 @@ struct Engine {
   // (merged with the bounds seen so far for the stage), with safety factors; if the iteration stalls or
   // grows, the solve is finished by GMRES.  Same stopping rule as GMRES: ||M r|| <= rtol ||M r_0||.
   std::vector<double> ch_lmin, ch_lmax;
+  std::vector<long> ch_count;
   double* chd = nullptr;
   int cheb_gmres(const double* qstar, double gamma, int didx, const double* b, double* x) {
     const double rtol = cfg.tent_rtol;
     if ((int)ch_lmin.size() < s + 1) { ch_lmin.assign(s + 1, -1.0); ch_lmax.assign(s + 1, -1.0); }
     if (!chd) chd = dalloc(NQ);
+    if ((int)ch_count.size() < s + 1) ch_count.assign(s + 1, 0);
     std::vector<double> ritz;
-    double beta0 = 0.0, beta = 0.0;
-    int its = gmres(qstar, gamma, didx, b, x, rtol, cfg.tent_maxit, true, &ritz, 6, &beta0, &beta);
-    if (beta <= rtol * beta0 || beta0 == 0.0) return its;
-    double lo = 1e300, hi = -1e300;
-    for (double v : ritz) { lo = std::min(lo, v); hi = std::max(hi, v); }
-    if (!(lo > 0) || !(hi > lo)) return its + gmres(qstar, gamma, didx, b, x, rtol, cfg.tent_maxit, true, nullptr, 0, nullptr, nullptr, beta0);
-    // Ritz values lie inside the spectrum: widen; keep the widest interval seen for this stage
-    lo *= 0.8; hi *= 1.15;
-    if (ch_lmin[didx] > 0) { lo = std::min(lo, ch_lmin[didx]); hi = std::max(hi, ch_lmax[didx]); }
-    ch_lmin[didx] = lo; ch_lmax[didx] = hi;
+    double beta0 = 0.0, beta = 0.0, lo, hi;
+    int its = 0;
+    const bool estimate = ch_lmin[didx] <= 0 || (ch_count[didx] % 16) == 0;
+    ch_count[didx]++;
+    if (estimate) {
+      its = gmres(qstar, gamma, didx, b, x, rtol, cfg.tent_maxit, true, &ritz, 6, &beta0, &beta);
+      if (beta <= rtol * beta0 || beta0 == 0.0) return its;
+      lo = 1e300; hi = -1e300;
+      for (double v : ritz) { lo = std::min(lo, v); hi = std::max(hi, v); }
+      if (!(lo > 0) || !(hi > lo)) return its + gmres(qstar, gamma, didx, b, x, rtol, cfg.tent_maxit, true, nullptr, 0, nullptr, nullptr, beta0);
+      // Ritz values lie inside the spectrum: widen; keep the widest interval seen for this stage
+      lo *= 0.8; hi *= 1.15;
+      if (ch_lmin[didx] > 0) { lo = std::min(lo, ch_lmin[didx]); hi = std::max(hi, ch_lmax[didx]); }
+      ch_lmin[didx] = lo; ch_lmax[didx] = hi;
+    } else {
+      // bounds of this stage are known (refreshed every 16th solve): start the Chebyshev iteration at once
+      lo = ch_lmin[didx]; hi = ch_lmax[didx];
+      adv_apply(x, qstar, wQ2, gamma, b);
+      tent_precond(didx, wQ2, wQ1);
+      beta0 = beta = std::sqrt(dot(NQ, wQ1, wQ1, KC));
+      if (!(beta0 == beta0)) throw NotConverged{"Chebyshev: NaN residual"};
+      if (beta0 == 0.0) return 0;
+    }
     const double theta = 0.5 * (hi + lo), delta = 0.5 * (hi - lo), sigma = theta / delta;
     double rho = 1.0 / sigma;
     double* t = wQ2;
@@ -718,30 +746,33 @@ struct Engine {
     const double kap = hi / lo, rate = (std::sqrt(kap) - 1.0) / (std::sqrt(kap) + 1.0);
     const int expected = (int)(std::log(std::max(rtol * beta0 / beta, 1e-300)) / std::log(rate)) + 8;
     adv_apply(x, qstar, t, gamma, b);
-    tent_precond(didx, t, z);
-    k_cheb_update<<<nvb, 256, 0, stream>>>(NQ, chd, z, x, 0.0, 1.0 / theta);
+    tent_precond_cheb(didx, t, nullptr, chd, x, 0.0, 1.0 / theta);
     int k = 1;
     its++;
     double last = beta;
     while (true) {
+      // the norm of z_k = M(b - A x_k) is checked every 4th iteration: only then is z written out
+      const bool check = (k % 4 == 0);
+      const double rn = 1.0 / (2.0 * sigma - rho);
       adv_apply(x, qstar, t, gamma, b);
-      tent_precond(didx, t, z);
-      if (k % 4 == 0) {
+      tent_precond_cheb(didx, t, check ? z : nullptr, chd, x, rn * rho, 2.0 * rn / delta);
+      rho = rn;
+      k++;
+      its++;
+      if (check) {
         double nz = std::sqrt(dot(NQ, z, z, KC));
         if (!(nz == nz)) throw NotConverged{"Chebyshev: NaN residual"};
-        if (nz <= rtol * beta0) return its;
+        if (nz <= rtol * beta0) {
+          // z belongs to the iterate BEFORE the step just taken; that iterate had converged, and the
+          // extra Chebyshev step only reduces the error further
+          return its;
+        }
         if (nz > 1e3 * last || k > 2 * expected + 16 || its >= cfg.tent_maxit) {
-          // bounds were wrong for this system: forget them and finish with GMRES
-          ch_lmin[didx] = ch_lmax[didx] = -1.0;
+          ch_lmin[didx] = ch_lmax[didx] = -1.0;  // bounds were wrong for this system: finish with GMRES
           return its + gmres(qstar, gamma, didx, b, x, rtol, cfg.tent_maxit, true, nullptr, 0, nullptr, nullptr, beta0);
         }
         last = std::min(last, nz);
       }
-      const double rn = 1.0 / (2.0 * sigma - rho);
-      k_cheb_update<<<nvb, 256, 0, stream>>>(NQ, chd, z, x, rn * rho, 2.0 * rn / delta);
-      rho = rn;
-      k++;
-      its++;
     }
   }
 
@@ -1264,6 +1295,12 @@ struct Engine {
         case 1: trace_apply(curL, nullptr, 0.0, 1.0, wL1); break;
         case 2: bdm(curQ, wQ1); break;
         case 3: backsub(curQ, curP, curL, wQ1, wP1); break;
+        case 4:  // second half of the two-level preconditioner fused with the Chebyshev step
+          ensure_dinv(1 % s, 0.25 * cfg.dt);
+          if (!chd) chd = dalloc(NQ);
+          bdm_plus_bj(wQ3, nullptr, wQ2, dinv0[1 % s], dinv1[1 % s], chd, wQ4, 0.5, 0.1);
+          break;
+        case 5: bdm_T(curQ, wQ1); break;
         default: throw std::string("unknown kernel id");
       }
     };

@@ -140,10 +140,14 @@ __device__ __forceinline__ void mv_acc_ld(const double* __restrict__ A, int LD, 
 //   with (In, Out) = (Lift^T, N^T) it is its transpose (used by the two-level preconditioner).
 // ------------------------------------------------------------------------------------------
 //   Optional fused epilogue (two-level preconditioner): out += Dinv_s * r_K  (element block-Jacobi).
+//   Optional Chebyshev epilogue (chd != nullptr): with z the kernel's result,
+//   d = c1*d + c2*z ; x += d ; z itself is stored only if out != nullptr (needed for norm checks).
 template <int K, bool TRANSPOSE, bool ADD_BJ>
 __global__ __launch_bounds__(128) void k_edge_lift(Geo g, DevTables T, const double* __restrict__ in,
                                                     double* __restrict__ out, const double* __restrict__ r,
-                                                    const double* __restrict__ Dinv0, const double* __restrict__ Dinv1) {
+                                                    const double* __restrict__ Dinv0, const double* __restrict__ Dinv1,
+                                                    double* __restrict__ chd, double* __restrict__ chx, double c1,
+                                                    double c2) {
   constexpr int NU = Dim<K>::NU, NE = Dim<K>::NE, N2 = 2 * NU;
   HDG_CELL_PROLOGUE
   double x[N2], y[N2];
@@ -174,7 +178,16 @@ __global__ __launch_bounds__(128) void k_edge_lift(Geo g, DevTables T, const dou
     }
     mv_acc<N2, NE>(Out, d, y, 1.0);
   }
-  store_cell<N2>(out, g.Nc, c, y);
+  if (out) store_cell<N2>(out, g.Nc, c, y);
+  if (chd) {
+#pragma unroll
+    for (int n = 0; n < N2; n++) {
+      const long idx = (long)n * g.Nc + c;
+      const double dn = (c1 != 0.0) ? fma(c1, chd[idx], c2 * y[n]) : c2 * y[n];
+      chd[idx] = dn;
+      chx[idx] += dn;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------
