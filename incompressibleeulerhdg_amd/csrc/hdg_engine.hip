@@ -827,6 +827,18 @@ struct Engine {
     zero(mg_x[lev], nv);
     static const int nsw = std::getenv("HDG_MG_SWEEPS") ? std::atoi(std::getenv("HDG_MG_SWEEPS")) : 2;
     static const int ncoarse = std::getenv("HDG_MG_COARSE") ? std::atoi(std::getenv("HDG_MG_COARSE")) : 6;
+    static const bool use_tail = !std::getenv("HDG_MG_NO_TAIL");
+    if (use_tail && n <= 32) {
+      // all remaining levels fit one workgroup's LDS: run the tail of the V-cycle in a single kernel
+      P1Tail tl;
+      tl.nlev = 0;
+      long tot = 0;
+      for (int l = lev; l < (int)mg_n.size() && tl.nlev < 8; l++) { tl.n[tl.nlev++] = mg_n[l]; tot += (long)(mg_n[l] + 1) * (mg_n[l] + 1); }
+      if (tot <= HDG_P1_TAIL_MAX && lev + tl.nlev == (int)mg_n.size()) {
+        k_p1_vcycle_tail<<<1, 1024, 0, stream>>>(tl, mg_b[lev], mg_x[lev], nsw, ncoarse);
+        return;
+      }
+    }
     if (lev == (int)mg_n.size() - 1) {
       p1_smooth(lev, ncoarse, false);
       p1_smooth(lev, ncoarse, true);

@@ -1133,6 +1133,103 @@ __global__ void k_fill(long N, double* __restrict__ x, double v) {
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < N; idx += stride) x[idx] = v;
 }
 
+// ------------------------------------------------------------------------------------------
+// The coarse tail of the V-cycle (all levels with n <= 32, i.e. <= 33^2 vertices) in ONE workgroup with
+// every level resident in LDS: replaces ~70 launches of 1-4 us kernels per V-cycle by one.
+// Same algorithm as the per-level kernels: V(nsw,nsw) with red-black Gauss-Seidel (colours swapped on
+// the way up), residual restriction by the transpose of the nested P1 interpolation, ncoarse+ncoarse
+// sweeps on the coarsest level.
+// ------------------------------------------------------------------------------------------
+struct P1Tail {
+  int nlev;
+  int n[8];
+};
+__device__ __forceinline__ void p1_stencil_lds(const double* x, int n, int i, int j, double& diag, double& off) {
+  const int st = n + 1;
+  const double wx = (j == 0 || j == n) ? 0.5 : 1.0;
+  const double wy = (i == 0 || i == n) ? 0.5 : 1.0;
+  diag = 0.0;
+  off = 0.0;
+  if (i > 0) { diag += wx; off += wx * x[j * st + i - 1]; }
+  if (i < n) { diag += wx; off += wx * x[j * st + i + 1]; }
+  if (j > 0) { diag += wy; off += wy * x[(j - 1) * st + i]; }
+  if (j < n) { diag += wy; off += wy * x[(j + 1) * st + i]; }
+}
+__device__ __forceinline__ void p1_sweeps_lds(double* x, const double* b, int n, int sweeps, bool reverse) {
+  const int npts = (n + 1) * (n + 1);
+  for (int sw = 0; sw < 2 * sweeps; sw++) {
+    const int colour = ((sw & 1) == 0) ? (reverse ? 1 : 0) : (reverse ? 0 : 1);
+    for (int p = threadIdx.x; p < npts; p += blockDim.x) {
+      const int j = p / (n + 1), i = p - j * (n + 1);
+      if (((i + j) & 1) == colour) {
+        double diag, off;
+        p1_stencil_lds(x, n, i, j, diag, off);
+        x[p] = (b[p] + off) / diag;
+      }
+    }
+    __syncthreads();
+  }
+}
+__device__ __forceinline__ double p1_res_lds(const double* x, const double* b, int n, int i, int j) {
+  double diag, off;
+  p1_stencil_lds(x, n, i, j, diag, off);
+  return b[j * (n + 1) + i] - (diag * x[j * (n + 1) + i] - off);
+}
+#define HDG_P1_TAIL_MAX 1600
+__global__ __launch_bounds__(1024) void k_p1_vcycle_tail(P1Tail tl, const double* __restrict__ b_in,
+                                                          double* __restrict__ x_out, int nsw, int ncoarse) {
+  __shared__ double X[HDG_P1_TAIL_MAX];
+  __shared__ double B[HDG_P1_TAIL_MAX];
+  int offs[9];
+  offs[0] = 0;
+  for (int l = 0; l < tl.nlev; l++) offs[l + 1] = offs[l] + (tl.n[l] + 1) * (tl.n[l] + 1);
+  for (int p = threadIdx.x; p < offs[1]; p += blockDim.x) B[p] = b_in[p];
+  for (int p = threadIdx.x; p < offs[tl.nlev]; p += blockDim.x) X[p] = 0.0;
+  __syncthreads();
+  for (int l = 0; l < tl.nlev - 1; l++) {
+    const int n = tl.n[l], nc = tl.n[l + 1];
+    double* x = X + offs[l];
+    const double* b = B + offs[l];
+    p1_sweeps_lds(x, b, n, nsw, false);
+    double* bc = B + offs[l + 1];
+    for (int p = threadIdx.x; p < (nc + 1) * (nc + 1); p += blockDim.x) {
+      const int J = p / (nc + 1), I = p - J * (nc + 1), i = 2 * I, j = 2 * J;
+      double acc = p1_res_lds(x, b, n, i, j);
+      if (i > 0) acc += 0.5 * p1_res_lds(x, b, n, i - 1, j);
+      if (i < n) acc += 0.5 * p1_res_lds(x, b, n, i + 1, j);
+      if (j > 0) acc += 0.5 * p1_res_lds(x, b, n, i, j - 1);
+      if (j < n) acc += 0.5 * p1_res_lds(x, b, n, i, j + 1);
+      if (i > 0 && j < n) acc += 0.5 * p1_res_lds(x, b, n, i - 1, j + 1);
+      if (i < n && j > 0) acc += 0.5 * p1_res_lds(x, b, n, i + 1, j - 1);
+      bc[p] = acc;
+    }
+    __syncthreads();
+  }
+  {
+    const int l = tl.nlev - 1;
+    p1_sweeps_lds(X + offs[l], B + offs[l], tl.n[l], ncoarse, false);
+    p1_sweeps_lds(X + offs[l], B + offs[l], tl.n[l], ncoarse, true);
+  }
+  for (int l = tl.nlev - 2; l >= 0; l--) {
+    const int n = tl.n[l], nc = tl.n[l + 1], sc = nc + 1;
+    double* x = X + offs[l];
+    const double* xc = X + offs[l + 1];
+    for (int p = threadIdx.x; p < (n + 1) * (n + 1); p += blockDim.x) {
+      const int j = p / (n + 1), i = p - j * (n + 1);
+      const int I = i >> 1, J = j >> 1;
+      double v;
+      if (!(i & 1) && !(j & 1)) v = xc[J * sc + I];
+      else if ((i & 1) && !(j & 1)) v = 0.5 * (xc[J * sc + I] + xc[J * sc + I + 1]);
+      else if (!(i & 1) && (j & 1)) v = 0.5 * (xc[J * sc + I] + xc[(J + 1) * sc + I]);
+      else v = 0.5 * (xc[J * sc + I + 1] + xc[(J + 1) * sc + I]);
+      x[p] += v;
+    }
+    __syncthreads();
+    p1_sweeps_lds(x, B + offs[l], n, nsw, true);
+  }
+  for (int p = threadIdx.x; p < offs[1]; p += blockDim.x) x_out[p] = X[p];
+}
+
 // trace <-> P1 transfer: P = edge-wise L2 projection of the P1 function (hdg_imex.py:491-503,
 // without the reference's 1/2 on interior edges - a preconditioner detail)
 __global__ void k_p1_to_trace(Geo g, int NL, const double* __restrict__ xc, double* __restrict__ l, double accumulate,
