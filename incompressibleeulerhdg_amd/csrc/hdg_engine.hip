@@ -745,8 +745,13 @@ struct Engine {
     // expected iterations for the remaining reduction (asymptotic Chebyshev rate), used as a stall guard
     const double kap = hi / lo, rate = (std::sqrt(kap) - 1.0) / (std::sqrt(kap) + 1.0);
     const int expected = (int)(std::log(std::max(rtol * beta0 / beta, 1e-300)) / std::log(rate)) + 8;
-    adv_apply(x, qstar, t, gamma, b);
-    tent_precond_cheb(didx, t, nullptr, chd, x, 0.0, 1.0 / theta);
+    if (estimate) {
+      adv_apply(x, qstar, t, gamma, b);
+      tent_precond_cheb(didx, t, nullptr, chd, x, 0.0, 1.0 / theta);
+    } else {
+      // z = M(b - A x) of the unchanged iterate is already in wQ1 (= z) from the norm evaluation above
+      k_cheb_update<<<nvb, 256, 0, stream>>>(NQ, chd, z, x, 0.0, 1.0 / theta);
+    }
     int k = 1;
     its++;
     double last = beta;
