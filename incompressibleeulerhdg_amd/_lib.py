@@ -175,7 +175,6 @@ class Engine:
         cfg.tau = float(kw.get("tau", 1.0))
         cfg.alpha_penalty = float(kw.get("alpha_penalty", 1.0))
         cfg.nstages = s
-        a_e = np.zeros((HDG_MAX_STAGES, HDG_MAX_STAGES))
         for name in ("a_expl", "a_impl"):
             m = np.zeros(s * s)
             if name in kw:
@@ -187,7 +186,6 @@ class Engine:
                 v = np.asarray(kw[name], dtype=float).reshape(-1)
                 for i in range(min(len(v), n if name != "b_impl" else HDG_MAX_STAGES + 1)):
                     getattr(cfg, name)[i] = v[i]
-        del a_e
         cfg.equispaced_nodes = 1 if kw.get("node_variant", "gll") == "equispaced" else 0
         cfg.tent_rtol = float(kw.get("tent_rtol", 1e-10))
         cfg.tent_maxit = int(kw.get("tent_maxit", 2000))

@@ -67,12 +67,6 @@ struct Engine {
   std::vector<void*> allocs;
   std::string err;
 
-  // device pointer tables for k_edge_lift
-  const double** d_tabN = nullptr;
-  const double** d_tabLift = nullptr;
-  const double** d_tabLiftT = nullptr;
-  const double** d_tabNt = nullptr;
-
   // state (modal, device)
   double *curQ, *curP, *curL;
   std::vector<double*> stQ, stP, stL, Qstar, Qtent, brhs;  // brhs has s+1 slots (last = b_new)
@@ -90,7 +84,6 @@ struct Engine {
   const double** d_gmV = nullptr;  // device array of the GMRES basis pointers
   double* d_part = nullptr;
   double* d_res = nullptr;
-  double* d_coef = nullptr;
   int dot_blocks = 0;
   // element block-Jacobi inverses per stage (depends on gamma = a_ii dt)
   std::vector<double*> dinv0, dinv1;
@@ -195,7 +188,6 @@ struct Engine {
 
   void build_dev_tables() {
     const Tables& T = *tab;
-    std::vector<const double*> pN, pL, pLT, pNt;
     for (int sh = 0; sh < 2; sh++) {
       for (int e = 0; e < 3; e++) {
         dt.N[sh][e] = upload(T.N[sh][e]);
@@ -206,8 +198,6 @@ struct Engine {
         dt.ePhi[sh][e] = upload(T.ePhi[sh][e]);
         dt.eGx[sh][e] = upload(T.eGx[sh][e]);
         dt.eGy[sh][e] = upload(T.eGy[sh][e]);
-        pN.push_back(dt.N[sh][e]); pL.push_back(dt.Lift[sh][e]);
-        pLT.push_back(dt.LiftT[sh][e]); pNt.push_back(dt.Nt[sh][e]);
       }
       dt.B[sh] = upload(T.B[sh]); dt.D0[sh] = upload(T.D0[sh]);
       dt.Ainv[sh] = upload(T.Ainv[sh]); dt.W[sh] = upload(T.W[sh]);
@@ -223,7 +213,6 @@ struct Engine {
     for (int e = 0; e < 3; e++) { dt.elen[e] = T.elen[e]; dt.enx[e] = T.enx[e]; dt.eny[e] = T.eny[e]; }
     for (int sh = 0; sh < 2; sh++) for (int e = 0; e < 3; e++) dt.sig[sh][e] = T.sig[sh][e];
     dt.h = T.h; dt.tau = T.tau; dt.alpha = T.alpha; dt.nqc = T.nqc; dt.nqe = T.nqe;
-    d_tabN = upload_ptrs(pN); d_tabLift = upload_ptrs(pL); d_tabLiftT = upload_ptrs(pLT); d_tabNt = upload_ptrs(pNt);
   }
 
   void alloc_state() {
@@ -259,7 +248,6 @@ struct Engine {
     dot_blocks = 1024;
     d_part = dalloc((long)dot_blocks * MAXV);
     d_res = dalloc(MAXV);
-    d_coef = dalloc(MAXV);
     hQ_dev = dalloc(NQb); hP_dev = dalloc(NPb);
     hL_dev = dalloc(NLb);
     {
@@ -433,17 +421,6 @@ struct Engine {
     multidot(n, a, {b}, &r, kind);
     return r;
   }
-  void multiaxpy(long n, double* w, const std::vector<const double*>& V, const std::vector<double>& h, double sign) {
-    int nv = (int)V.size();
-    for (int off = 0; off < nv; off += MAXV) {
-      int cnt = std::min(MAXV, nv - off);
-      HIPCHECK(hipMemcpyAsync((void*)d_ptrs, V.data() + off, sizeof(double*) * cnt, hipMemcpyHostToDevice, stream));
-      HIPCHECK(hipMemcpyAsync(d_coef, h.data() + off, sizeof(double) * cnt, hipMemcpyHostToDevice, stream));
-      k_multiaxpy<MAXV><<<vec_blocks(n), 256, 0, stream>>>(n, w, d_ptrs, d_coef, cnt, sign);
-      HIPCHECK(hipStreamSynchronize(stream));  // d_ptrs / d_coef are reused by the next call
-    }
-  }
-
   // ------------------------------------------------------------------ pressure mean shift
   void shift(double* p, double* l) {
     const double c0 = g.h / std::sqrt(2.0);  // integral of the mode-0 basis function = its "1" coefficient

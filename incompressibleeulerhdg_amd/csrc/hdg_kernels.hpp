@@ -999,20 +999,6 @@ __global__ void k_reduce_parts(int nblocks, int nv, const double* __restrict__ p
     res[k] = tot;
   }
 }
-// w -= sum_k h[k] V[k]
-template <int MAXV>
-__global__ void k_multiaxpy(long N, double* __restrict__ w, const double* const* __restrict__ V,
-                            const double* __restrict__ hcoef, int nv, double sign) {
-  const long stride = (long)gridDim.x * blockDim.x;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < N; idx += stride) {
-    double acc = w[idx];
-#pragma unroll
-    for (int k = 0; k < MAXV; k++)
-      if (k < nv) acc = fma(sign * hcoef[k], V[k][idx], acc);
-    w[idx] = acc;
-  }
-}
-
 // Chebyshev step on velocity vectors:  d = c1*d + c2*z ;  x += d
 __global__ void k_cheb_update(long N, double* __restrict__ d, const double* __restrict__ z, double* __restrict__ x,
                               double c1, double c2) {
