@@ -1,0 +1,72 @@
+"""Size-independent properties at the BASELINE sizes, where the oracle cannot run (C2: k=1, 256^2;
+C3: k=2, 1024^2).  Each property holds for any correct implementation of the reference's forms."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _stepper(k, nx, **kw):
+    from incompressibleeulerhdg_amd.mesh import UnitSquareMesh
+    from incompressibleeulerhdg_amd.model_problems import TaylorGreen
+    from incompressibleeulerhdg_amd.timesteppers import IncompressibleEulerHDGIMEXSSP2_332
+
+    ts = IncompressibleEulerHDGIMEXSSP2_332(UnitSquareMesh(nx, nx), k, 0.25 / nx, use_projection_method=True, n_richardson=2, **kw)
+    return ts, TaylorGreen(ts._V_Q, ts._V_p, "exponential", 0.5)
+
+
+@pytest.mark.parametrize("k,nx", [(1, 256), (2, 1024)])
+def test_operator_properties_at_baseline_size(hip_lib, k, nx):
+    ts, mp = _stepper(k, nx)
+    e = ts._engine
+    rng = np.random.default_rng(123456789)
+    x = rng.standard_normal(e.shape_Q)
+    y = rng.standard_normal(e.shape_Q)
+    # BDM projection: idempotent, and the projection of an interpolated smooth H(div) field is itself
+    Px = e.project_bdm_nodal(x)
+    PPx = e.project_bdm_nodal(Px)
+    assert np.max(np.abs(PPx - Px)) < 1e-10 * np.max(np.abs(Px))
+    Qs = ts._V_Q.interpolate(mp.Q_stationary)
+    assert np.max(np.abs(e.project_bdm_nodal(Qs) - Qs)) < 1e-11
+    # advection operator: linear in x; reduces to the identity for gamma = 0
+    a, b = 0.7, -1.3
+    gamma = 0.25 * 0.25 / nx
+    lhs = e.apply_advection(Px, a * x + b * y, gamma)
+    rhs = a * e.apply_advection(Px, x, gamma) + b * e.apply_advection(Px, y, gamma)
+    assert np.max(np.abs(lhs - rhs)) < 1e-10 * np.max(np.abs(rhs))
+    assert np.max(np.abs(e.apply_advection(Px, x, 0.0) - x)) < 1e-12 * np.max(np.abs(x))
+    # condensed trace operator: constants are in the null space (hdg_imex.py:480-489); the weak divergence
+    # of any field sums to zero against psi = 1 (consistency of the stage right-hand sides)
+    lam = np.ones(e.shape_l)
+    T1 = e.apply_trace_operator(lam)
+    Tr = e.apply_trace_operator(rng.standard_normal(e.shape_l))
+    assert np.max(np.abs(T1)) < 1e-9 * np.max(np.abs(Tr))
+    wd = e.apply_weak_divergence(x)
+    assert abs(e.integrate_pressure(wd)) < 1e-9 * np.max(np.abs(wd))
+    # nodal <-> modal round trip through the device
+    e.set_field(1, x, None, None)
+    assert np.max(np.abs(e.get_field(1, p=False, lam=False)[0] - x)) < 1e-12 * np.max(np.abs(x))
+
+
+@pytest.mark.parametrize("k,nx,nsteps", [(1, 256, 3), (2, 1024, 2)])
+def test_timestep_properties_at_baseline_size(hip_lib, k, nx, nsteps):
+    from incompressibleeulerhdg_amd import _lib
+
+    ts, mp = _stepper(k, nx)
+    e = ts._engine
+    dt = 0.25 / nx
+    Q, p = ts.solve(*mp.initial_condition(), None, mp.f_rhs(), nsteps * dt, fused=True)
+    # zero-mean pressure after every shift (hdg_imex.py:471-478)
+    assert abs(e.integrate_pressure(p.dat.data)) < 1e-11
+    # the manufactured vortex decays like exp(-kappa t): discretisation error only (h^{k+2}, dt)
+    Qe, pe = mp.solution(nsteps * dt, e.integrate_pressure)
+    eq, ep = e.l2_norms(Q.dat.data - Qe.dat.data, p.dat.data - pe.dat.data)
+    nq, _ = e.l2_norms(Qe.dat.data, pe.dat.data)
+    assert eq < 1e-6 * nq and ep < 1e-4
+    # Q* used in the last stage is H(div) conforming with zero boundary flux: a fixed point of the projection
+    Qstar = e.get_field(200 + 1, p=False, lam=False)[0]
+    assert np.max(np.abs(e.project_bdm_nodal(Qstar) - Qstar)) < 1e-10 * np.max(np.abs(Qstar))
+    # mesh-independent Krylov behaviour (the design claim behind the two-level preconditioners)
+    sums, cnt = e.iteration_stats()
+    its = sums / np.maximum(cnt, 1)
+    assert its[0] < 70 and np.all(its[1:] < 20), its
