@@ -75,7 +75,7 @@ def main():
     ap.add_argument("--tent-precond", type=int, default=1)
     ap.add_argument("--trace-precond", type=int, default=1)
     ap.add_argument("--gmres-restart", type=int, default=8)
-    ap.add_argument("--tent-solver", type=int, default=1, help="0 GMRES, 1 GMRES cycle + Chebyshev")
+    ap.add_argument("--tent-solver", type=int, default=None, help="0 GMRES, 1 GMRES cycle + Chebyshev (default: by degree)")
     ap.add_argument("--comm", choices=["rccl", "shm"], default="rccl", help="inter-rank transport for --gpus > 1")
     args = ap.parse_args()
 
@@ -142,7 +142,7 @@ def main():
         return IncompressibleEulerHDGIMEXSSP2_332(
             UnitSquareMesh(nx, nx), k, dt, use_projection_method=True, n_richardson=2, device=local_rank,
             tent_precond=args.tent_precond, trace_precond=args.trace_precond, gmres_restart=args.gmres_restart,
-            tent_solver=args.tent_solver, **comm_kwargs(backend, rank, world, token))
+            **({} if args.tent_solver is None else {"tent_solver": args.tent_solver}), **comm_kwargs(backend, rank, world, token))
 
     backend = args.comm if world > 1 else "none"
     if world > 1 and backend == "rccl":

@@ -705,6 +705,11 @@ struct Engine {
       lo *= 0.8; hi *= 1.15;
       if (ch_lmin[didx] > 0) { lo = std::min(lo, ch_lmin[didx]); hi = std::max(hi, ch_lmax[didx]); }
       ch_lmin[didx] = lo; ch_lmax[didx] = hi;
+      if (std::getenv("HDG_DEBUG")) {
+        fprintf(stderr, "[cheb] stage %d ritz:", didx);
+        for (double v : ritz) fprintf(stderr, " %.3f", v);
+        fprintf(stderr, "  -> interval [%.3f, %.3f], after GMRES cycle residual %.2e of %.2e\n", lo, hi, beta, beta0);
+      }
     } else {
       // bounds of this stage are known (refreshed every 16th solve): start the Chebyshev iteration at once
       lo = ch_lmin[didx]; hi = ch_lmax[didx];
@@ -744,6 +749,7 @@ struct Engine {
       if (check) {
         double nz = std::sqrt(dot(NQ, z, z, KC));
         if (!(nz == nz)) throw NotConverged{"Chebyshev: NaN residual"};
+        if (std::getenv("HDG_DEBUG")) fprintf(stderr, "[cheb]   k=%d  |Mr|/|Mr0| = %.3e\n", k, nz / beta0);
         if (nz <= rtol * beta0) {
           // z belongs to the iterate BEFORE the step just taken; that iterate had converged, and the
           // extra Chebyshev step only reduces the error further
