@@ -90,6 +90,7 @@ struct Engine {
   std::vector<double> dinv_gamma;
   // trace Chebyshev bounds
   double cheb_lmin = 0, cheb_lmax = 0;
+  double tr_one_nn = -1.0;
   // operator sets of the hybridised mixed Poisson problem, one per stabilisation parameter tau':
   // set 0 (tau) serves the projection method; the unsplit solves use tau/gamma (see mono_precond)
   struct PSet { DevTables dt; double lmin, lmax, tau; };
@@ -784,8 +785,9 @@ struct Engine {
   // ------------------------------------------------------------------ trace solver
   void project_const(double* x) {
     // x <- x - n (n.x)/(n.n), n = trace coefficients of the constant 1 (null space, hdg_imex.py:480-489)
-    double nn = dot(NLv, tr_one, tr_one, KL), nx_ = dot(NLv, tr_one, x, KL);
-    axpby(NLv, -nx_ / nn, tr_one, 1.0, x);
+    if (tr_one_nn < 0) tr_one_nn = dot(NLv, tr_one, tr_one, KL);  // = total skeleton length, constant
+    const double nx_ = dot(NLv, tr_one, x, KL);
+    axpby(NLv, -nx_ / tr_one_nn, tr_one, 1.0, x);
   }
   void cheb_smooth(const double* b, double* x, bool zero_init, int its) {
     const double theta = 0.5 * (cheb_lmax + cheb_lmin), delta = 0.5 * (cheb_lmax - cheb_lmin);
