@@ -694,16 +694,20 @@ struct Engine {
     std::vector<double> ritz;
     double beta0 = 0.0, beta = 0.0, lo, hi;
     int its = 0;
-    const bool estimate = ch_lmin[didx] <= 0 || (ch_count[didx] % 16) == 0;
+    static const int est_every = std::getenv("HDG_CHEB_EVERY") ? std::atoi(std::getenv("HDG_CHEB_EVERY")) : 16;
+    static const int head_m = std::getenv("HDG_CHEB_M") ? std::atoi(std::getenv("HDG_CHEB_M")) : 6;
+    const bool estimate = ch_lmin[didx] <= 0 || (ch_count[didx] % est_every) == 0;
     ch_count[didx]++;
     if (estimate) {
-      its = gmres(qstar, gamma, didx, b, x, rtol, cfg.tent_maxit, true, &ritz, 6, &beta0, &beta);
+      its = gmres(qstar, gamma, didx, b, x, rtol, cfg.tent_maxit, true, &ritz, head_m, &beta0, &beta);
       if (beta <= rtol * beta0 || beta0 == 0.0) return its;
       lo = 1e300; hi = -1e300;
       for (double v : ritz) { lo = std::min(lo, v); hi = std::max(hi, v); }
       if (!(lo > 0) || !(hi > lo)) return its + gmres(qstar, gamma, didx, b, x, rtol, cfg.tent_maxit, true, nullptr, 0, nullptr, nullptr, beta0);
       // Ritz values lie inside the spectrum: widen; keep the widest interval seen for this stage
-      lo *= 0.8; hi *= 1.15;
+      static const double f_lo = std::getenv("HDG_CHEB_FLO") ? std::atof(std::getenv("HDG_CHEB_FLO")) : 0.8;
+      static const double f_hi = std::getenv("HDG_CHEB_FHI") ? std::atof(std::getenv("HDG_CHEB_FHI")) : 1.15;
+      lo *= f_lo; hi *= f_hi;
       if (ch_lmin[didx] > 0) { lo = std::min(lo, ch_lmin[didx]); hi = std::max(hi, ch_lmax[didx]); }
       ch_lmin[didx] = lo; ch_lmax[didx] = hi;
       if (std::getenv("HDG_DEBUG")) {
@@ -758,6 +762,7 @@ struct Engine {
         }
         if (nz > 1e3 * last || k > 2 * expected + 16 || its >= cfg.tent_maxit) {
           ch_lmin[didx] = ch_lmax[didx] = -1.0;  // bounds were wrong for this system: finish with GMRES
+          if (std::getenv("HDG_DEBUG")) fprintf(stderr, "[cheb]   falling back to GMRES at k=%d (|Mr| %.2e, best %.2e)\n", k, nz, last);
           return its + gmres(qstar, gamma, didx, b, x, rtol, cfg.tent_maxit, true, nullptr, 0, nullptr, nullptr, beta0);
         }
         last = std::min(last, nz);

@@ -105,3 +105,29 @@ def test_reproducible_bitwise(hip_lib):
         Q, p = ts.solve(*mp.initial_condition(), None, mp.f_rhs(), 0.5 / 16, fused=True)
         out.append((Q.dat.data.copy(), p.dat.data.copy()))
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+
+
+def test_chebyshev_with_wrong_bounds_falls_back_to_gmres(hip_lib, tmp_path):
+    """The Chebyshev phase of the tentative solver is driven by estimated spectral bounds.  With the
+    upper bound deliberately halved (HDG_CHEB_FHI=0.5) the iteration diverges; the solver must notice,
+    finish with GMRES and still deliver the converged answer (parity with the oracle)."""
+    import os
+    import subprocess
+    import sys
+
+    from oracle import hdg_oracle as orc
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = str(tmp_path / "r.npz")
+    k, nx, nsteps = 2, 8, 2
+    env = dict(os.environ, HDG_CHEB_FHI="0.5", HDG_DEBUG="1")
+    r = subprocess.run([sys.executable, os.path.join(here, "mp_strip_worker.py"), "0", "1", "unused", str(k), str(nx),
+                        str(nsteps), out], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    assert r.returncode == 0, r.stdout.decode()[-2000:]
+    got = np.load(out)
+    d = orc.HDGDiscretisation(nx, k)
+    tg = orc.TaylorGreen(d)
+    dt = 0.25 / nx
+    oQ, op = orc.OracleHDGIMEX(d, dt, "imex_ssp2_332").solve(*tg.initial_condition(), tg.f_rhs, nsteps * dt)
+    assert _rel(got["Q"], oQ) < 2e-8 and _rel(got["p"], op) < 2e-8
+    assert "falling back to GMRES" in r.stdout.decode()
