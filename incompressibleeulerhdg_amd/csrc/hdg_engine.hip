@@ -1264,6 +1264,7 @@ struct Engine {
     HIPCHECK(hipStreamSynchronize(stream));
   }
   void get_L(double* modal, double* host) {
+    halo_L(modal);  // the strip's top row is a ghost copy on every rank but the topmost
     l_to_nodal(modal, hL_dev);
     HIPCHECK(hipMemcpyAsync(host, hL_dev, sizeof(double) * n_edges() * NL, hipMemcpyDeviceToHost, stream));
     HIPCHECK(hipStreamSynchronize(stream));

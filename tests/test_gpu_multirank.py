@@ -48,7 +48,10 @@ def _assemble(parts, k, nx):
     for r, d in enumerate(parts):
         lam = d["lam"].reshape(-1, nl)
         h = lam[:NH_l].reshape(nyl + 1, nx, nl)
-        H.append(h if r == P - 1 else h[:-1])  # the top row of a lower rank duplicates the upper rank's bottom row
+        if r < P - 1:  # the top row of a lower rank duplicates the upper rank's bottom row
+            upper = parts[r + 1]["lam"].reshape(-1, nl)[:NH_l].reshape(nyl + 1, nx, nl)
+            assert np.allclose(h[-1], upper[0], rtol=0, atol=1e-13)
+        H.append(h if r == P - 1 else h[:-1])
         V.append(lam[NH_l:NH_l + NV_l])
         D.append(lam[NH_l + NV_l:])
     lam = np.concatenate([np.concatenate(H).reshape(-1, nl), np.concatenate(V), np.concatenate(D)]).ravel()
