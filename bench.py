@@ -72,7 +72,7 @@ def main():
     ap.add_argument("--nx", type=int, default=1024)
     ap.add_argument("--degree", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--tent-precond", type=int, default=1)
+    ap.add_argument("--tent-precond", type=int, default=2)
     ap.add_argument("--trace-precond", type=int, default=1)
     ap.add_argument("--gmres-restart", type=int, default=8)
     ap.add_argument("--tent-solver", type=int, default=None, help="0 GMRES, 1 GMRES cycle + Chebyshev (default: by degree)")
@@ -188,35 +188,40 @@ def main():
             ("tentative", "pressure", "final_pressure", "pressure_reconstruction"), sums, cnt)}
         ntot = eng.n_total
         value = ntot * args.steps / elapsed / 1e6
-        # --- roofline of the dominant kernel.  With the Chebyshev tentative solver the kernel with the
-        # largest share of the step (38 %, profiles/r01_e_*) is k_edge_lift<K,false,true>: BDM lift Pi +
-        # element block-Jacobi + Chebyshev update in one pass.  Algorithmic bytes per launch: it reads
-        # 4 velocity vectors (lift input, residual, direction d, iterate x) and writes 2 (d, x), 8 B per
-        # entry; duration from HIP events on the engine's stream.
+        # --- roofline of the dominant kernel.  The kernel with the largest share of the step (28 % in
+        # profiles/r01_h_kernel_stats_c3_hybrid.csv) is the tentative-velocity preconditioner fused with the
+        # Chebyshev update: k_edge_lift<K,false,2> (BDM lift Pi, element block-Jacobi of the non-conforming
+        # remainder, d = c1 d + c2 z, x += d in one pass).  Algorithmic bytes per launch: it reads 3 velocity
+        # vectors (residual, direction d, iterate x) and writes 2 (d, x), 8 B per entry (SURVEY.md section
+        # 8d); with the additive preconditioner (--tent-precond 1) the kernel is k_edge_lift<K,false,1>
+        # and reads one vector more.  Duration from HIP events on the engine's stream.
         NQ = eng.n_cells * 2 * eng.n_u  # this rank's strip: kernel timings below are per-rank launches
         NL = eng.n_edges * eng.n_l
         NP = eng.n_cells * eng.n_p
-        ms_lift = eng.time_kernel(4, 20)
-        ms_adv = eng.time_kernel(0, 20)
+        hybrid = args.tent_precond == 2
+        ms_lift = eng.time_kernel(6 if hybrid else 4, 20)
+        ms_adv = eng.time_kernel(7, 20)
         ms_liftT = eng.time_kernel(5, 20)
         ms_tr = eng.time_kernel(1, 50)
         ms_bs = eng.time_kernel(3, 20)
-        lift_bytes = 8.0 * 6 * NQ
+        lift_bytes = 8.0 * (5 if hybrid else 6) * NQ
+        lift_name = ("k_edge_lift<K,false,2> (BDM lift + block-Jacobi of the remainder + Chebyshev step)" if hybrid
+                     else "k_edge_lift<K,false,1> (BDM lift + block-Jacobi + Chebyshev step)")
         traffic = None
         try:  # HBM bytes per launch from the committed PMC passes (same workload, single rank only)
             tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            if tj["workload"] == {"nx": nx, "degree": k} and world == 1:
-                traffic = tj["kernels"]["k_edge_lift<false,true>+cheb"]["hbm_bytes"]
+            if tj["workload"] == {"nx": nx, "degree": k} and world == 1 and hybrid:
+                traffic = tj["kernels"]["k_edge_lift<K,false,2>+cheb"]["hbm_bytes"]
         except Exception:
             traffic = None
         gbs = lambda b, ms: b / (ms * 1e-3) / 1e9
-        roof = dict(bound="hbm", kernel="k_edge_lift<K,false,true> (BDM lift + block-Jacobi + Chebyshev step)",
+        roof = dict(bound="hbm", kernel=lift_name,
                     achieved=gbs(lift_bytes, ms_lift), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=gbs(lift_bytes, ms_lift) / HBM_PEAK_GBS, traffic=traffic, algorithmic_bytes=lift_bytes,
                     ms_per_launch=ms_lift,
                     other_kernels={
-                        "k_adv_apply": dict(ms=ms_adv, GBs=gbs(8.0 * 3 * NQ, ms_adv)),
-                        "k_edge_lift<K,true,false>": dict(ms=ms_liftT, GBs=gbs(8.0 * 2 * NQ, ms_liftT)),
+                        "k_adv_apply (residual form)": dict(ms=ms_adv, GBs=gbs(8.0 * 4 * NQ, ms_adv)),
+                        "k_edge_lift<K,true,0>": dict(ms=ms_liftT, GBs=gbs(8.0 * 2 * NQ, ms_liftT)),
                         "k_trace_apply": dict(ms=ms_tr, GBs=gbs(8.0 * 2 * NL, ms_tr)),
                         "k_backsub": dict(ms=ms_bs, GBs=gbs(8.0 * (NL + 2 * NQ + 2 * NP), ms_bs)),
                     })

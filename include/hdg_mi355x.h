@@ -67,7 +67,8 @@ typedef struct hdg_config {
   double tent_rtol;      /* 1e-10 (hdg_imex.py:226) */
   int tent_maxit;
   int gmres_restart;     /* PETSc default 30 */
-  int tent_precond;      /* 0 element block-Jacobi, 1 two-level (block-Jacobi + BDM-conforming correction) */
+  int tent_precond;      /* 0 element block-Jacobi; 1 additive two-level  Dinv + Pi Pi^T;
+                          * 2 hybrid two-level  Pi + Dinv (I - Pi)  (Pi = BDM projection), one kernel */
   int tent_solver;       /* 0 restarted GMRES, 1 one GMRES cycle (Ritz bounds) + Chebyshev iteration, GMRES fallback */
   double trace_rtol;     /* 1e-12 (hdg_imex.py:137) */
   int trace_maxit;
@@ -168,7 +169,9 @@ int hdg_apply_weak_divergence(hdg_handle* h, const double* Q, int broken, double
 /* device-resident micro-benchmarks for bench.py: run `reps` launches of one kernel on the internal
  * stream, return the average milliseconds per launch measured with HIP events on that stream.
  * kernel: 0 advection apply, 1 trace apply, 2 BDM projection, 3 back-substitution,
- *         4 BDM lift + block-Jacobi + Chebyshev step (fused), 5 transposed BDM lift */
+ *         4 BDM lift + block-Jacobi + Chebyshev step (fused; additive preconditioner), 5 transposed BDM lift,
+ *         6 hybrid preconditioner (BDM lift + block-Jacobi of the remainder) + Chebyshev step (fused),
+ *         7 advection apply in residual form  b - (I - gamma F) x */
 int hdg_time_kernel(hdg_handle* h, int kernel, int reps, double* ms_per_launch);
 
 #ifdef __cplusplus

@@ -190,10 +190,14 @@ class Engine:
         cfg.tent_rtol = float(kw.get("tent_rtol", 1e-10))
         cfg.tent_maxit = int(kw.get("tent_maxit", 2000))
         cfg.gmres_restart = int(kw.get("gmres_restart", 8))
-        cfg.tent_precond = int(kw.get("tent_precond", 1))
-        # Chebyshev wins in wall time for k <= 3; at k = 4 the register-bound fused lift kernel makes
-        # restarted GMRES faster (measured at nx = 512: 1417 vs 1568 ms/step), see DESIGN.md section 6
-        cfg.tent_solver = int(kw.get("tent_solver", 1 if int(kw["degree"]) <= 3 else 0))
+        # hybrid two-level preconditioner Pi + Dinv (I - Pi): one lift kernel per application
+        cfg.tent_precond = int(kw.get("tent_precond", 2))
+        # with the hybrid preconditioner GMRES(8) needs 24-43 iterations where the Chebyshev iteration needs
+        # 38-65 (fat, non-real spectrum); Chebyshev still wins in wall time for k <= 2, where the Krylov
+        # basis traffic outweighs the operator (nx = 512, ms/step Chebyshev vs GMRES: k=1 53/67, k=2 80/86,
+        # k=3 232/206, k=4 560/498), see DESIGN.md section 6
+        _cheb_default = 1 if int(kw["degree"]) <= (2 if cfg.tent_precond == 2 else 3) else 0
+        cfg.tent_solver = int(kw.get("tent_solver", _cheb_default))
         cfg.trace_rtol = float(kw.get("trace_rtol", 1e-12))
         cfg.trace_maxit = int(kw.get("trace_maxit", 10000))
         cfg.trace_precond = int(kw.get("trace_precond", 1))

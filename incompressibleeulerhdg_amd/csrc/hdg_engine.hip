@@ -288,17 +288,24 @@ struct Engine {
 
   void bdm(const double* in, double* out) {
     halo_Q(in);
-    HDG_DISPATCH(k_edge_lift<KK, false, false><<<cell_grid(), bs(), 0, stream>>>(g, dt, in, out, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, 0.0));
+    HDG_DISPATCH(k_edge_lift<KK, false, 0><<<cell_grid(), bs(), 0, stream>>>(g, dt, in, out, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, 0.0));
   }
   // out = Pi(in) + Dinv r   (second half of the two-level preconditioner, block-Jacobi fused in)
   void bdm_plus_bj(const double* in, double* out, const double* r, const double* D0, const double* D1,
                    double* chd_ = nullptr, double* chx_ = nullptr, double c1 = 0.0, double c2 = 0.0) {
     halo_Q(in);
-    HDG_DISPATCH(k_edge_lift<KK, false, true><<<cell_grid(), bs(), 0, stream>>>(g, dt, in, out, r, D0, D1, chd_, chx_, c1, c2));
+    HDG_DISPATCH(k_edge_lift<KK, false, 1><<<cell_grid(), bs(), 0, stream>>>(g, dt, in, out, r, D0, D1, chd_, chx_, c1, c2));
+  }
+  // hybrid two-level preconditioner in ONE kernel: out = Pi(in) + Dinv (in - Pi(in)), optionally fused with
+  // the Chebyshev step
+  void bdm_hybrid(const double* in, double* out, const double* D0, const double* D1, double* chd_ = nullptr,
+                  double* chx_ = nullptr, double c1 = 0.0, double c2 = 0.0) {
+    halo_Q(in);
+    HDG_DISPATCH(k_edge_lift<KK, false, 2><<<cell_grid(), bs(), 0, stream>>>(g, dt, in, out, nullptr, D0, D1, chd_, chx_, c1, c2));
   }
   void bdm_T(const double* in, double* out) {
     halo_Q(in);
-    HDG_DISPATCH(k_edge_lift<KK, true, false><<<cell_grid(), bs(), 0, stream>>>(g, dt, in, out, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, 0.0));
+    HDG_DISPATCH(k_edge_lift<KK, true, 0><<<cell_grid(), bs(), 0, stream>>>(g, dt, in, out, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, 0.0));
   }
   void adv_apply(const double* x, const double* qstar, double* out, double gamma, const double* bsub = nullptr) {
     halo_Q(x);
@@ -494,9 +501,11 @@ struct Engine {
   void tent_precond(int didx, const double* r, double* z) {
     if (cfg.tent_precond == 0) {
       blockdiag(dinv0[didx], dinv1[didx], r, nullptr, 0.0, z);
-    } else {
+    } else if (cfg.tent_precond == 1) {
       bdm_T(r, wQ3);
       bdm_plus_bj(wQ3, z, r, dinv0[didx], dinv1[didx]);
+    } else {
+      bdm_hybrid(r, z, dinv0[didx], dinv1[didx]);
     }
   }
   // z = M r fused with the Chebyshev step d = c1 d + c2 z, x += d (owned rows only: the ghost rows of x are
@@ -506,19 +515,21 @@ struct Engine {
       blockdiag(dinv0[didx], dinv1[didx], r, nullptr, 0.0, wQ4);
       if (zout) copy(zout, wQ4, NQ);
       k_cheb_update<<<vec_blocks(NQ), 256, 0, stream>>>(NQ, d_, wQ4, x_, c1, c2);
-    } else {
+    } else if (cfg.tent_precond == 1) {
       bdm_T(r, wQ3);
       bdm_plus_bj(wQ3, zout, r, dinv0[didx], dinv1[didx], d_, x_, c1, c2);
+    } else {
+      bdm_hybrid(r, zout, dinv0[didx], dinv1[didx], d_, x_, c1, c2);
     }
   }
   // solve (I - gamma F(Q*)) x = b with left-preconditioned GMRES(m); x holds the initial guess.
   // Convergence: ||M r|| <= rtol * ||M r0||  (PETSc default for the SNES-ksponly linear solve the
   // reference performs: relative to the residual at the warm start)
-  // ritz != nullptr: run ONE cycle of at most m_cycle iterations, return the eigenvalue real parts of
+  // ritz != nullptr: run ONE cycle of at most m_cycle iterations, return the eigenvalues of
   // its Hessenberg matrix (Ritz values of the preconditioned operator) and the initial / final
   // preconditioned residual norms through *beta_first / *beta_last (beta_last is the Arnoldi estimate).
   int gmres(const double* qstar, double gamma, int didx, const double* b, double* x, double rtol = -1.0,
-            int maxit = -1, bool strict = true, std::vector<double>* ritz = nullptr, int m_cycle = 0,
+            int maxit = -1, bool strict = true, std::vector<std::complex<double>>* ritz = nullptr, int m_cycle = 0,
             double* beta_first = nullptr, double* beta_last = nullptr, double beta0_given = -1.0) {
     const int m = std::min(std::max(1, cfg.gmres_restart), MAXV - 1);  // allocated basis / Hessenberg stride
     // adaptive cycle length: short cycles keep the Krylov-basis traffic low (the preconditioned operator
@@ -617,7 +628,7 @@ struct Engine {
         // Ritz values: eigenvalues of the leading j x j block of the (unrotated) Hessenberg matrix
         std::vector<double> Hs((size_t)j * j);
         for (int a = 0; a < j; a++) for (int c = 0; c < j; c++) Hs[(size_t)a * j + c] = Hraw[(size_t)a * m + c];
-        *ritz = hessenberg_eig_real(Hs, j);
+        *ritz = hessenberg_eig(Hs, j);
         return its;
       }
       if (done) return its;
@@ -628,21 +639,21 @@ struct Engine {
     }
   }
 
-  // real parts of the eigenvalues of a small upper Hessenberg matrix: shifted QR iteration in complex
-  // arithmetic with deflation (n <= 32, used for Ritz values only)
-  static std::vector<double> hessenberg_eig_real(const std::vector<double>& Hin, int n) {
+  // eigenvalues of a small upper Hessenberg matrix: shifted QR iteration in complex arithmetic with
+  // deflation (n <= 32, used for Ritz values only)
+  static std::vector<std::complex<double>> hessenberg_eig(const std::vector<double>& Hin, int n) {
     typedef std::complex<double> cd;
     std::vector<cd> H((size_t)n * n);
     for (int i = 0; i < n * n; i++) H[i] = Hin[i];
-    std::vector<double> ev;
+    std::vector<cd> ev;
     int hi = n - 1;
     int guard = 0;
     while (hi >= 0 && guard++ < 10000) {
-      if (hi == 0) { ev.push_back(H[0].real()); break; }
+      if (hi == 0) { ev.push_back(H[0]); break; }
       // deflate
       double sub = std::abs(H[(size_t)hi * n + hi - 1]);
       double diag = std::abs(H[(size_t)hi * n + hi]) + std::abs(H[(size_t)(hi - 1) * n + hi - 1]);
-      if (sub <= 1e-14 * (diag > 0 ? diag : 1.0)) { ev.push_back(H[(size_t)hi * n + hi].real()); hi--; continue; }
+      if (sub <= 1e-14 * (diag > 0 ? diag : 1.0)) { ev.push_back(H[(size_t)hi * n + hi]); hi--; continue; }
       // Wilkinson shift from the trailing 2x2 block
       cd a = H[(size_t)(hi - 1) * n + hi - 1], b = H[(size_t)(hi - 1) * n + hi], c = H[(size_t)hi * n + hi - 1], d = H[(size_t)hi * n + hi];
       cd tr = a + d, det = a * d - b * c, disc = std::sqrt(tr * tr - 4.0 * det);
@@ -685,13 +696,15 @@ struct Engine {
   // grows, the solve is finished by GMRES.  Same stopping rule as GMRES: ||M r|| <= rtol ||M r_0||.
   std::vector<double> ch_lmin, ch_lmax;
   std::vector<long> ch_count;
+  std::vector<double> ch_widen;
   double* chd = nullptr;
   int cheb_gmres(const double* qstar, double gamma, int didx, const double* b, double* x) {
     const double rtol = cfg.tent_rtol;
     if ((int)ch_lmin.size() < s + 1) { ch_lmin.assign(s + 1, -1.0); ch_lmax.assign(s + 1, -1.0); }
     if (!chd) chd = dalloc(NQ);
     if ((int)ch_count.size() < s + 1) ch_count.assign(s + 1, 0);
-    std::vector<double> ritz;
+    if ((int)ch_widen.size() < s + 1) ch_widen.assign(s + 1, 1.0);
+    std::vector<std::complex<double>> ritz;
     double beta0 = 0.0, beta = 0.0, lo, hi;
     int its = 0;
     static const int est_every = std::getenv("HDG_CHEB_EVERY") ? std::atoi(std::getenv("HDG_CHEB_EVERY")) : 16;
@@ -702,17 +715,24 @@ struct Engine {
       its = gmres(qstar, gamma, didx, b, x, rtol, cfg.tent_maxit, true, &ritz, head_m, &beta0, &beta);
       if (beta <= rtol * beta0 || beta0 == 0.0) return its;
       lo = 1e300; hi = -1e300;
-      for (double v : ritz) { lo = std::min(lo, v); hi = std::max(hi, v); }
+      for (auto v : ritz) { lo = std::min(lo, v.real()); hi = std::max(hi, v.real()); }
       if (!(lo > 0) || !(hi > lo)) return its + gmres(qstar, gamma, didx, b, x, rtol, cfg.tent_maxit, true, nullptr, 0, nullptr, nullptr, beta0);
       // Ritz values lie inside the spectrum: widen; keep the widest interval seen for this stage
-      static const double f_lo = std::getenv("HDG_CHEB_FLO") ? std::atof(std::getenv("HDG_CHEB_FLO")) : 0.8;
-      static const double f_hi = std::getenv("HDG_CHEB_FHI") ? std::atof(std::getenv("HDG_CHEB_FHI")) : 1.15;
+      // (the hybrid preconditioner's real spectrum starts at 1 -- the non-conforming part is reproduced exactly
+      //  -- but its upper end, 4.2-5.5 for k = 1..3, is underestimated by 6 Arnoldi steps, ~3.2; the ellipse of
+      //  convergence is larger than the interval, so 1.3 is enough for k >= 2 (1.5 for k = 1), and a stage whose Chebyshev
+      //  iteration had to fall back to GMRES widens its own factor for all later solves: ch_widen)
+      const bool hyb = cfg.tent_precond == 2;
+      static const double e_lo = std::getenv("HDG_CHEB_FLO") ? std::atof(std::getenv("HDG_CHEB_FLO")) : -1.0;
+      static const double e_hi = std::getenv("HDG_CHEB_FHI") ? std::atof(std::getenv("HDG_CHEB_FHI")) : -1.0;
+      const double f_lo = e_lo > 0 ? e_lo : (hyb ? 0.9 : 0.8);
+      const double f_hi = (e_hi > 0 ? e_hi : (hyb ? (cfg.degree == 1 ? 1.5 : 1.3) : 1.15)) * ch_widen[didx];
       lo *= f_lo; hi *= f_hi;
       if (ch_lmin[didx] > 0) { lo = std::min(lo, ch_lmin[didx]); hi = std::max(hi, ch_lmax[didx]); }
       ch_lmin[didx] = lo; ch_lmax[didx] = hi;
       if (std::getenv("HDG_DEBUG")) {
         fprintf(stderr, "[cheb] stage %d ritz:", didx);
-        for (double v : ritz) fprintf(stderr, " %.3f", v);
+        for (auto v : ritz) fprintf(stderr, " %.3f%+.3fi", v.real(), v.imag());
         fprintf(stderr, "  -> interval [%.3f, %.3f], after GMRES cycle residual %.2e of %.2e\n", lo, hi, beta, beta0);
       }
     } else {
@@ -724,14 +744,23 @@ struct Engine {
       if (!(beta0 == beta0)) throw NotConverged{"Chebyshev: NaN residual"};
       if (beta0 == 0.0) return 0;
     }
-    const double theta = 0.5 * (hi + lo), delta = 0.5 * (hi - lo), sigma = theta / delta;
+    // Chebyshev for a spectrum inside the ellipse with centre theta, real half-axis a and imaginary
+    // half-axis bim: foci at theta +- delta, delta^2 = a^2 - bim^2.  The additive preconditioner (SPD)
+    // gives a nearly real spectrum (bim = 0 is best); the hybrid one is non-symmetric and its spectrum fills
+    // a fat ellipse (at 128^2: real [1, 4.8] / [1, 4.2] / [1, 5.5], |imag| <= 1.2 / 1.4 / 2.2 for k = 1 / 2 / 3):
+    // bim = 0.5 a is within a few iterations of the best value for k = 1, 2 (measured scan), while
+    // bim = 0 loses 10+ iterations.
+    static const double ell = std::getenv("HDG_CHEB_ELL") ? std::atof(std::getenv("HDG_CHEB_ELL")) : -1.0;
+    const double frac = ell >= 0 ? ell : (cfg.tent_precond == 2 ? 0.5 : 0.0);
+    const double theta = 0.5 * (hi + lo), aax = 0.5 * (hi - lo), bim = frac * aax;
+    const double delta = std::sqrt(std::max(aax * aax - bim * bim, 1e-24)), sigma = theta / delta;
     double rho = 1.0 / sigma;
     double* t = wQ2;
     double* z = wQ1;
     const int nvb = vec_blocks(NQ);
-    // expected iterations for the remaining reduction (asymptotic Chebyshev rate), used as a stall guard
-    const double kap = hi / lo, rate = (std::sqrt(kap) - 1.0) / (std::sqrt(kap) + 1.0);
-    const int expected = (int)(std::log(std::max(rtol * beta0 / beta, 1e-300)) / std::log(rate)) + 8;
+    // expected iterations for the remaining reduction (asymptotic rate on the ellipse), used as a stall guard
+    const double rate = (aax + bim) / (theta + std::sqrt(std::max(theta * theta - delta * delta, 0.0)));
+    const int expected = (int)(std::log(std::max(rtol * beta0 / beta, 1e-300)) / std::log(std::min(rate, 0.999))) + 8;
     if (estimate) {
       adv_apply(x, qstar, t, gamma, b);
       tent_precond_cheb(didx, t, nullptr, chd, x, 0.0, 1.0 / theta);
@@ -761,7 +790,8 @@ struct Engine {
           return its;
         }
         if (nz > 1e3 * last || k > 2 * expected + 16 || its >= cfg.tent_maxit) {
-          ch_lmin[didx] = ch_lmax[didx] = -1.0;  // bounds were wrong for this system: finish with GMRES
+          ch_lmin[didx] = ch_lmax[didx] = -1.0;  // bounds were wrong for this system: finish with GMRES,
+          ch_widen[didx] = std::min(ch_widen[didx] * 1.25, 4.0);  // and estimate more generously next time
           if (std::getenv("HDG_DEBUG")) fprintf(stderr, "[cheb]   falling back to GMRES at k=%d (|Mr| %.2e, best %.2e)\n", k, nz, last);
           return its + gmres(qstar, gamma, didx, b, x, rtol, cfg.tent_maxit, true, nullptr, 0, nullptr, nullptr, beta0);
         }
@@ -1309,6 +1339,12 @@ struct Engine {
           bdm_plus_bj(wQ3, nullptr, wQ2, dinv0[1 % s], dinv1[1 % s], chd, wQ4, 0.5, 0.1);
           break;
         case 5: bdm_T(curQ, wQ1); break;
+        case 6:  // hybrid two-level preconditioner (one lift + block-Jacobi of the remainder) + Chebyshev step
+          ensure_dinv(1 % s, 0.25 * cfg.dt);
+          if (!chd) chd = dalloc(NQ);
+          bdm_hybrid(wQ2, nullptr, dinv0[1 % s], dinv1[1 % s], chd, wQ4, 0.5, 0.1);
+          break;
+        case 7: adv_apply(curQ, Qstar[0], wQ1, 0.25 * cfg.dt, wQ2); break;  // residual form b - A x
         default: throw std::string("unknown kernel id");
       }
     };

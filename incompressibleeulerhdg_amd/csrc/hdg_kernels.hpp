@@ -139,10 +139,13 @@ __device__ __forceinline__ void mv_acc_ld(const double* __restrict__ A, int LD, 
 //   With (In, Out) = (N, Lift) this is the BDM projection Q -> Q* (common.py:91-108);
 //   with (In, Out) = (Lift^T, N^T) it is its transpose (used by the two-level preconditioner).
 // ------------------------------------------------------------------------------------------
-//   Optional fused epilogue (two-level preconditioner): out += Dinv_s * r_K  (element block-Jacobi).
+//   ADD_BJ = 1 (additive two-level preconditioner): result += Dinv_s * r_K  with a separate vector r.
+//   ADD_BJ = 2 (hybrid two-level preconditioner M = Pi + Dinv (I - Pi), one kernel): with y = Pi(in),
+//              result = y + Dinv_s * (in_K - y_K): the conforming part of the residual is kept as is, the
+//              non-conforming remainder goes through the element block-Jacobi.
 //   Optional Chebyshev epilogue (chd != nullptr): with z the kernel's result,
 //   d = c1*d + c2*z ; x += d ; z itself is stored only if out != nullptr (needed for norm checks).
-template <int K, bool TRANSPOSE, bool ADD_BJ>
+template <int K, bool TRANSPOSE, int ADD_BJ>
 __global__ __launch_bounds__(128) void k_edge_lift(Geo g, DevTables T, const double* __restrict__ in,
                                                     double* __restrict__ out, const double* __restrict__ r,
                                                     const double* __restrict__ Dinv0, const double* __restrict__ Dinv1,
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(128) void k_edge_lift(Geo g, DevTables T, const dou
   load_cell<N2>(in, g.Nc, c, x);
 #pragma unroll
   for (int n = 0; n < N2; n++) y[n] = x[n];
-  if (ADD_BJ) {
+  if (ADD_BJ == 1) {
     double rr[N2];
     load_cell<N2>(r, g.Nc, c, rr);
     mv_acc<N2, N2>(s == 0 ? Dinv0 : Dinv1, rr, y, 1.0);
@@ -177,6 +180,11 @@ __global__ __launch_bounds__(128) void k_edge_lift(Geo g, DevTables T, const dou
       for (int a = 0; a < NE; a++) d[a] *= 0.5;
     }
     mv_acc<N2, NE>(Out, d, y, 1.0);
+  }
+  if (ADD_BJ == 2) {
+#pragma unroll
+    for (int n = 0; n < N2; n++) x[n] -= y[n];  // non-conforming remainder (I - Pi) in
+    mv_acc<N2, N2>(s == 0 ? Dinv0 : Dinv1, x, y, 1.0);
   }
   if (out) store_cell<N2>(out, g.Nc, c, y);
   if (chd) {

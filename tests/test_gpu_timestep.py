@@ -83,9 +83,12 @@ def test_centered_flux_constant_forcing_richardson1(hip_lib):
         assert _relerr(a, b) < TOL, name
 
 
-@pytest.mark.parametrize("tp,trp", [(0, 0), (1, 0), (0, 1)])
-def test_preconditioner_choice_does_not_change_the_answer(hip_lib, tp, trp):
-    got, ref, *_ = _run_pair(1, 8, "imex_ssp2_332", 1, tent_precond=tp, trace_precond=trp)
+@pytest.mark.parametrize("tp,trp,solver", [(0, 0, 1), (1, 0, 1), (0, 1, 1), (1, 1, 1), (1, 1, 0), (2, 1, 0),
+                                            (2, 0, 1)])
+def test_preconditioner_choice_does_not_change_the_answer(hip_lib, tp, trp, solver):
+    """tent_precond 0 / 1 / 2 (block-Jacobi, additive, hybrid two-level), trace_precond 0 / 1 and the
+    Krylov method (0 GMRES, 1 GMRES cycle + Chebyshev) only change the iteration counts."""
+    got, ref, *_ = _run_pair(1, 8, "imex_ssp2_332", 1, tent_precond=tp, trace_precond=trp, tent_solver=solver)
     for a, b, name in zip(got, ref, "Qpl"):
         assert _relerr(a, b) < TOL, name
 
