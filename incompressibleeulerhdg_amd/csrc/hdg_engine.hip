@@ -849,7 +849,6 @@ struct Engine {
   void vcycle(int lev) {
     int n = mg_n[lev];
     long nv = (long)(n + 1) * (n + 1);
-    zero(mg_x[lev], nv);
     static const int nsw = std::getenv("HDG_MG_SWEEPS") ? std::atoi(std::getenv("HDG_MG_SWEEPS")) : 2;
     static const int ncoarse = std::getenv("HDG_MG_COARSE") ? std::atoi(std::getenv("HDG_MG_COARSE")) : 6;
     static const bool use_tail = !std::getenv("HDG_MG_NO_TAIL");
@@ -865,10 +864,34 @@ struct Engine {
       }
     }
     if (lev == (int)mg_n.size() - 1) {
+      zero(mg_x[lev], nv);
       p1_smooth(lev, ncoarse, false);
       p1_smooth(lev, ncoarse, true);
       return;
     }
+    static const bool fuse_legs = !std::getenv("HDG_MG_NO_FUSE");
+    if (fuse_legs && nsw >= 1 && nsw <= HDG_P1_MAXSW && (n & 1) == 0) {
+      // one kernel per leg (LDS tiles with recomputed halos), bit-identical to the launches below
+      const int nt = (n + 1 + HDG_P1_TS - 1) / HDG_P1_TS;
+      const dim3 gt(nt, nt);
+      auto down = [&](auto tag) {
+        constexpr int NSW = decltype(tag)::value;
+        k_p1_down<NSW><<<gt, HDG_P1_THREADS, 0, stream>>>(n, mg_b[lev], mg_r[lev], mg_b[lev + 1]);
+      };
+      auto up = [&](auto tag) {
+        constexpr int NSW = decltype(tag)::value;
+        k_p1_up<NSW><<<gt, HDG_P1_THREADS, 0, stream>>>(n, mg_x[lev + 1], mg_b[lev], mg_r[lev], mg_x[lev]);
+      };
+      if (nsw == 1) down(std::integral_constant<int, 1>{});
+      else if (nsw == 2) down(std::integral_constant<int, 2>{});
+      else down(std::integral_constant<int, 3>{});
+      vcycle(lev + 1);
+      if (nsw == 1) up(std::integral_constant<int, 1>{});
+      else if (nsw == 2) up(std::integral_constant<int, 2>{});
+      else up(std::integral_constant<int, 3>{});
+      return;
+    }
+    zero(mg_x[lev], nv);
     p1_smooth(lev, nsw, false);
     dim3 grid((n + 1 + 63) / 64, n + 1);
     k_p1_residual<<<grid, 64, 0, stream>>>(n, mg_x[lev], mg_b[lev], mg_r[lev]);

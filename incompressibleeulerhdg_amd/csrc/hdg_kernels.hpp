@@ -1128,6 +1128,133 @@ __global__ void k_fill(long N, double* __restrict__ x, double v) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Fused legs of one V-cycle level (levels too large for the LDS tail below).  Per level the unfused path
+// is 12 launches of ~6 us latency-bound kernels (fill, 2 nsw half sweeps, residual, restriction | prolongation,
+// 2 nsw half sweeps); here each leg is ONE kernel: a workgroup holds a TS x TS tile of vertices plus a halo in
+// LDS and recomputes the halo (temporal blocking; a half sweep has dependency radius 1, so after m half
+// sweeps everything further than m from the edge of the loaded region is exact).  Every vertex value is
+// produced by the same expression in the same order as in k_p1_rbgs / k_p1_residual / k_p1_restrict /
+// k_p1_prolong_add, so the results are bit-identical to the unfused path.
+// ------------------------------------------------------------------------------------------
+#define HDG_P1_TS 32
+#define HDG_P1_MAXSW 3
+#define HDG_P1_THREADS 1024
+// region-local stencil: (gi, gj) global vertex, (li, lj) local; false if a neighbour inside the domain lies
+// outside the loaded region (the point is then part of the garbage ring and is skipped).
+// The diagonal is 4 (interior), 2 (boundary edge) or 1 (corner): its reciprocal is exact, so multiplying by
+// `inv` is bit-identical to the division in k_p1_rbgs.
+template <int W>
+__device__ __forceinline__ bool p1_stencil_tile(const double* X, int n, int gi, int gj, int li, int lj, double& diag,
+                                                double& off) {
+  const double wx = (gj == 0 || gj == n) ? 0.5 : 1.0;
+  const double wy = (gi == 0 || gi == n) ? 0.5 : 1.0;
+  diag = 0.0;
+  off = 0.0;
+  if ((gi > 0 && li == 0) || (gi < n && li == W - 1) || (gj > 0 && lj == 0) || (gj < n && lj == W - 1)) return false;
+  if (gi > 0) { diag += wx; off += wx * X[lj * W + li - 1]; }
+  if (gi < n) { diag += wx; off += wx * X[lj * W + li + 1]; }
+  if (gj > 0) { diag += wy; off += wy * X[(lj - 1) * W + li]; }
+  if (gj < n) { diag += wy; off += wy * X[(lj + 1) * W + li]; }
+  return true;
+}
+// 2 nsw half sweeps; each thread owns the q-th vertex of the active colour (W even: W/2 per row and colour)
+template <int W>
+__device__ __forceinline__ void p1_tile_sweeps(double* X, const double* B, int n, int gi0, int gj0, int nsw, bool reverse) {
+  for (int hs = 0; hs < 2 * nsw; hs++) {
+    const int colour = ((hs & 1) == 0) ? (reverse ? 1 : 0) : (reverse ? 0 : 1);
+    for (int q = threadIdx.x; q < W * W / 2; q += HDG_P1_THREADS) {
+      const int lj = q / (W / 2), li = 2 * (q - lj * (W / 2)) + ((colour + gi0 + gj0 + lj) & 1);
+      const int gi = gi0 + li, gj = gj0 + lj;
+      if (gi < 0 || gj < 0 || gi > n || gj > n) continue;
+      double diag, off;
+      if (p1_stencil_tile<W>(X, n, gi, gj, li, lj, diag, off)) {
+        const double inv = diag == 4.0 ? 0.25 : (diag == 2.0 ? 0.5 : 1.0 / diag);
+        X[lj * W + li] = (B[lj * W + li] + off) * inv;
+      }
+    }
+    __syncthreads();
+  }
+}
+// down leg: x = 0, nsw sweeps on A x = b, r = b - A x, bc = R r (coarse right-hand side); x is stored to xpre
+template <int NSW>
+__global__ __launch_bounds__(HDG_P1_THREADS) void k_p1_down(int n, const double* __restrict__ b, double* __restrict__ xpre,
+                                                            double* __restrict__ bc) {
+  constexpr int H = 2 * NSW + 2, W = HDG_P1_TS + 2 * H;
+  __shared__ double X[W * W];
+  __shared__ double B[W * W];
+  const int st = n + 1;
+  const int i0 = blockIdx.x * HDG_P1_TS, j0 = blockIdx.y * HDG_P1_TS, gi0 = i0 - H, gj0 = j0 - H;
+  for (int p = threadIdx.x; p < W * W; p += HDG_P1_THREADS) {
+    const int lj = p / W, li = p - lj * W, gi = gi0 + li, gj = gj0 + lj;
+    const bool in = gi >= 0 && gj >= 0 && gi <= n && gj <= n;
+    B[p] = in ? b[gj * st + gi] : 0.0;
+    X[p] = 0.0;
+  }
+  __syncthreads();
+  p1_tile_sweeps<W>(X, B, n, gi0, gj0, NSW, false);
+  // store the tile's x, then overwrite B by the residual (r_p needs b_p and x only)
+  {
+    const int p = threadIdx.x;  // HDG_P1_TS^2 == HDG_P1_THREADS
+    const int tj = p / HDG_P1_TS, ti = p - tj * HDG_P1_TS, gi = i0 + ti, gj = j0 + tj;
+    if (gi <= n && gj <= n) xpre[gj * st + gi] = X[(tj + H) * W + ti + H];
+  }
+  for (int p = threadIdx.x; p < W * W; p += HDG_P1_THREADS) {
+    const int lj = p / W, li = p - lj * W, gi = gi0 + li, gj = gj0 + lj;
+    if (gi < 0 || gj < 0 || gi > n || gj > n) continue;
+    double diag, off;
+    if (p1_stencil_tile<W>(X, n, gi, gj, li, lj, diag, off)) B[p] = B[p] - (diag * X[p] - off);
+  }
+  __syncthreads();
+  constexpr int HT = HDG_P1_TS / 2;
+  const int nc = n >> 1;
+  if (threadIdx.x < HT * HT) {
+    const int p = threadIdx.x;
+    const int tJ = p / HT, tI = p - tJ * HT, i = i0 + 2 * tI, j = j0 + 2 * tJ;
+    if (i <= n && j <= n) {
+      const int li = i - gi0, lj = j - gj0;
+      double acc = B[lj * W + li];
+      if (i > 0) acc += 0.5 * B[lj * W + li - 1];
+      if (i < n) acc += 0.5 * B[lj * W + li + 1];
+      if (j > 0) acc += 0.5 * B[(lj - 1) * W + li];
+      if (j < n) acc += 0.5 * B[(lj + 1) * W + li];
+      if (i > 0 && j < n) acc += 0.5 * B[(lj + 1) * W + li - 1];
+      if (i < n && j > 0) acc += 0.5 * B[(lj - 1) * W + li + 1];
+      bc[(j >> 1) * (nc + 1) + (i >> 1)] = acc;
+    }
+  }
+}
+// up leg: x = xpre + P xc, nsw sweeps with the colours reversed.  xpre (the down leg's result) and x are
+// DIFFERENT buffers: a workgroup reads the halo of its tile while its neighbours store theirs.
+template <int NSW>
+__global__ __launch_bounds__(HDG_P1_THREADS) void k_p1_up(int n, const double* __restrict__ xc, const double* __restrict__ b,
+                                                          const double* __restrict__ xpre, double* __restrict__ x) {
+  constexpr int H = 2 * NSW, W = HDG_P1_TS + 2 * H;
+  __shared__ double X[W * W];
+  __shared__ double B[W * W];
+  const int st = n + 1, nc = n >> 1, sc = nc + 1;
+  const int i0 = blockIdx.x * HDG_P1_TS, j0 = blockIdx.y * HDG_P1_TS, gi0 = i0 - H, gj0 = j0 - H;
+  for (int p = threadIdx.x; p < W * W; p += HDG_P1_THREADS) {
+    const int lj = p / W, li = p - lj * W, i = gi0 + li, j = gj0 + lj;
+    if (i < 0 || j < 0 || i > n || j > n) { X[p] = 0.0; B[p] = 0.0; continue; }
+    const int I = i >> 1, J = j >> 1;
+    double v;
+    if (!(i & 1) && !(j & 1)) v = xc[J * sc + I];
+    else if ((i & 1) && !(j & 1)) v = 0.5 * (xc[J * sc + I] + xc[J * sc + I + 1]);
+    else if (!(i & 1) && (j & 1)) v = 0.5 * (xc[J * sc + I] + xc[(J + 1) * sc + I]);
+    else v = 0.5 * (xc[J * sc + I + 1] + xc[(J + 1) * sc + I]);
+    X[p] = xpre[j * st + i] + v;
+    B[p] = b[j * st + i];
+  }
+  __syncthreads();
+  p1_tile_sweeps<W>(X, B, n, gi0, gj0, NSW, true);
+  {
+    const int p = threadIdx.x;
+    const int tj = p / HDG_P1_TS, ti = p - tj * HDG_P1_TS, gi = i0 + ti, gj = j0 + tj;
+    if (gi <= n && gj <= n) x[gj * st + gi] = X[(tj + H) * W + ti + H];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // The coarse tail of the V-cycle (all levels with n <= 32, i.e. <= 33^2 vertices) in ONE workgroup with
 // every level resident in LDS: replaces ~70 launches of 1-4 us kernels per V-cycle by one.
 // Same algorithm as the per-level kernels: V(nsw,nsw) with red-black Gauss-Seidel (colours swapped on

@@ -131,3 +131,29 @@ def test_chebyshev_with_wrong_bounds_falls_back_to_gmres(hip_lib, tmp_path):
     oQ, op = orc.OracleHDGIMEX(d, dt, "imex_ssp2_332").solve(*tg.initial_condition(), tg.f_rhs, nsteps * dt)
     assert _rel(got["Q"], oQ) < 2e-8 and _rel(got["p"], op) < 2e-8
     assert "falling back to GMRES" in r.stdout.decode()
+
+
+def test_fused_vcycle_kernels_are_bitwise_equal_to_the_per_level_launches(hip_lib, tmp_path):
+    """The P1 V-cycle of the trace preconditioner runs its legs as fused LDS-tile kernels (k_p1_down /
+    k_p1_up, levels with n > 32) and its tail in one workgroup (k_p1_vcycle_tail).  Both are pure
+    re-schedulings of the per-level launches: the whole time step must come out bit-identical with
+    either switched off.  nx = 128, 96: fused levels n = 128, 64 / 96 with partial tiles at the far boundary;
+    nx = 512: enough workgroups in flight that an in-place halo race between tiles shows (it did)."""
+    import os
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    for nx in (128, 96, 512):
+        res = {}
+        for tag, extra in (("fused", {}), ("unfused", {"HDG_MG_NO_FUSE": "1"}),
+                           ("plain", {"HDG_MG_NO_FUSE": "1", "HDG_MG_NO_TAIL": "1"})):
+            out = str(tmp_path / f"{tag}{nx}.npz")
+            r = subprocess.run([sys.executable, os.path.join(here, "mp_strip_worker.py"), "0", "1", "unused", "1", str(nx),
+                                "1", out], env=dict(os.environ, **extra), stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                               timeout=600)
+            assert r.returncode == 0, r.stdout.decode()[-2000:]
+            res[tag] = np.load(out)
+        for name in ("Q", "p", "lam", "its"):
+            assert np.array_equal(res["fused"][name], res["unfused"][name]), (nx, name)
+            assert np.array_equal(res["fused"][name], res["plain"][name]), (nx, name)
