@@ -329,8 +329,8 @@ struct Engine {
     halo_L(lam);
     HDG_DISPATCH(k_trace_apply<KK><<<corner_grid(), bs(), 0, stream>>>(g, pdt(), lam, base, cb, ct, out));
   }
-  void trace_cheb(const double* r, double* d, double* x, double c1, double c2) {
-    HDG_DISPATCH(k_trace_cheb<KK><<<corner_grid(), bs(), 0, stream>>>(g, pdt(), r, d, x, c1, c2));
+  void trace_cheb(const double* r, double* d, double* x, double c1, double c2, bool assign = false) {
+    HDG_DISPATCH(k_trace_cheb<KK><<<corner_grid(), bs(), 0, stream>>>(g, pdt(), r, d, x, c1, c2, assign ? 1 : 0));
   }
   void condense(const double* rw, const double* rp, const double* rl, double* out) {
     if (rw) halo_Q(rw);
@@ -411,16 +411,19 @@ struct Engine {
     return RowMask{g.nx, g.ny + 2, 1, g.ny};
   }
   // dots of w against nv vectors over the OWNED entries, summed over ranks (host result); one sync
-  void multidot(long n, const double* w, const std::vector<const double*>& V, double* res, int kind) {
+  // cross: res[nv] additionally receives (V[0], V[1]) from the same pass (nv >= 2, single chunk)
+  void multidot(long n, const double* w, const std::vector<const double*>& V, double* res, int kind, bool cross = false) {
     int nv = (int)V.size();
+    if (cross && (nv < 2 || nv >= MAXV)) throw std::string("multidot: cross product needs 2 <= nv < MAXV");
     for (int off = 0; off < nv; off += MAXV) {
       int cnt = std::min(MAXV, nv - off);
+      const int nout = cnt + (cross ? 1 : 0);
       HIPCHECK(hipMemcpyAsync((void*)d_ptrs, V.data() + off, sizeof(double*) * cnt, hipMemcpyHostToDevice, stream));
       int nb = std::min(dot_blocks, vec_blocks(n));
-      k_multidot<MAXV><<<nb, HDG_DOT_BLOCK, 0, stream>>>(n, w, d_ptrs, cnt, d_part, mask_for(kind));
-      k_reduce_parts<<<cnt, 256, 0, stream>>>(nb, cnt, d_part, d_res);
-      comm->allreduce_sum(d_res, cnt, stream);
-      HIPCHECK(hipMemcpyAsync(res + off, d_res, sizeof(double) * cnt, hipMemcpyDeviceToHost, stream));
+      k_multidot<MAXV><<<nb, HDG_DOT_BLOCK, 0, stream>>>(n, w, d_ptrs, cnt, d_part, mask_for(kind), cross ? 1 : 0);
+      k_reduce_parts<<<nout, 256, 0, stream>>>(nb, nout, d_part, d_res);
+      comm->allreduce_sum(d_res, nout, stream);
+      HIPCHECK(hipMemcpyAsync(res + off, d_res, sizeof(double) * nout, hipMemcpyDeviceToHost, stream));
       HIPCHECK(hipStreamSynchronize(stream));
     }
   }
@@ -434,7 +437,7 @@ struct Engine {
     const double c0 = g.h / std::sqrt(2.0);  // integral of the mode-0 basis function = its "1" coefficient
     const double vol = 1.0;                  // domain_volume (common.py:72-73)
     int nb = std::min(dot_blocks, vec_blocks(g.Nc));
-    k_multidot<MAXV><<<nb, HDG_DOT_BLOCK, 0, stream>>>(g.Nc, p, d_ones_ptr, 1, d_part, mask_for(KC));
+    k_multidot<MAXV><<<nb, HDG_DOT_BLOCK, 0, stream>>>(g.Nc, p, d_ones_ptr, 1, d_part, mask_for(KC), 0);
     k_reduce_parts<<<1, 256, 0, stream>>>(nb, 1, d_part, d_res);
     comm->allreduce_sum(d_res, 1, stream);
     k_shift_p<<<vec_blocks(g.Nc), 256, 0, stream>>>(g.Nc, p, d_res, c0 / vol, c0);
@@ -828,11 +831,12 @@ struct Engine {
     const double theta = 0.5 * (cheb_lmax + cheb_lmin), delta = 0.5 * (cheb_lmax - cheb_lmin);
     const double sigma1 = theta / delta;
     double rho = 1.0 / sigma1;
-    if (zero_init) { copy(ch_r, b, NLv); zero(x, NLv); }
-    else trace_apply(x, b, 1.0, -1.0, ch_r);
-    trace_cheb(ch_r, ch_d, x, 0.0, 1.0 / theta);
+    // zero initial guess: the first residual is b itself and the first step assigns x (no copy, no fill)
+    const double* r0 = b;
+    if (!zero_init) { trace_apply(x, b, 1.0, -1.0, ch_r); r0 = ch_r; }
+    trace_cheb(r0, ch_d, x, 0.0, 1.0 / theta, zero_init);
     for (int it = 1; it < its; it++) {
-      trace_apply(ch_d, ch_r, 1.0, -1.0, ch_r);
+      trace_apply(ch_d, it == 1 ? r0 : ch_r, 1.0, -1.0, ch_r);
       double rn = 1.0 / (2.0 * sigma1 - rho);
       trace_cheb(ch_r, ch_d, x, rn * rho, 2.0 * rn / delta);
       rho = rn;
@@ -1021,37 +1025,55 @@ struct Engine {
     project_const(b);
     trace_apply(x, b, 1.0, -1.0, cg_r);  // r = b - T x
     trace_precond(cg_r, cg_z);
-    project_const(cg_z);
-    double d2[2];
-    multidot(NLv, cg_z, {cg_r, cg_z}, d2, KL);
-    double rz = d2[0], norm0 = std::sqrt(d2[1]);
+    double rz, zz, c;
+    cg_dots(rz, zz, c);
+    double norm0 = std::sqrt(zz);
     if (!(norm0 == norm0)) throw NotConverged{"trace CG: NaN residual"};
     if (norm0 == 0.0) return 0;
-    copy(cg_p, cg_z, NLv);
+    const int nvb = vec_blocks(NLv);
+    k_cg_p<<<nvb, 256, 0, stream>>>(NLv, cg_z, tr_one, c, 0.0, cg_p);
     int its = 0;
     while (true) {
       trace_apply(cg_p, nullptr, 0.0, 1.0, cg_Ap);
       double pAp = dot(NLv, cg_p, cg_Ap, KL);
       if (!(pAp > 0)) throw NotConverged{"trace CG: breakdown (p.Ap <= 0)"};
       double alpha = rz / pAp;
-      axpby(NLv, alpha, cg_p, 1.0, x);
-      axpby(NLv, -alpha, cg_Ap, 1.0, cg_r);
+      k_cg_xr<<<nvb, 256, 0, stream>>>(NLv, alpha, cg_p, cg_Ap, x, cg_r);
       trace_precond(cg_r, cg_z);
-      project_const(cg_z);
-      multidot(NLv, cg_z, {cg_r, cg_z}, d2, KL);
+      double rz_new;
+      cg_dots(rz_new, zz, c);
       its++;
-      double nrm = std::sqrt(d2[1]);
+      double nrm = std::sqrt(zz);
+      if (std::getenv("HDG_DEBUG_CG")) fprintf(stderr, "[cg] it %d |z|/|z0| %.3e  c %.3e rz %.3e pAp %.3e\n", its, nrm / norm0, c, rz_new, pAp);
       if (nrm <= rtol * norm0) return its;
       if (its >= maxit) {
         if (strict) throw NotConverged{"trace CG reached max iterations"};
         return its;
       }
-      double beta = d2[0] / rz;
-      rz = d2[0];
-      axpby(NLv, 1.0, cg_z, beta, cg_p);
+      double beta = rz_new / rz;
+      rz = rz_new;
+      k_cg_p<<<nvb, 256, 0, stream>>>(NLv, cg_z, tr_one, c, beta, cg_p);
     }
   }
-
+  // inner products of the PROJECTED preconditioned residual z' = z - c n (n = null-space vector, c = (n,z)/(n,n))
+  // from one pass over z, r, n:  (z', r) = (z, r) - c (n, r),  (z', z') = (z, z) - c (n, z).  (n, r) vanishes
+  // only up to rounding, and that remainder matters once the residual has dropped by 1e-10: without the term the
+  // iteration loses orthogonality and diverges.  The projection itself is applied where z' is consumed (k_cg_p).
+  // If the subtraction in (z', z') cancels more than 6 digits the projection is done explicitly instead.
+  void cg_dots(double& rz, double& zz, double& c) {
+    if (tr_one_nn < 0) tr_one_nn = dot(NLv, tr_one, tr_one, KL);
+    double d3[4];
+    multidot(NLv, cg_z, {tr_one, cg_r, cg_z}, d3, KL, true);  // (z,n), (z,r), (z,z), (n,r)
+    c = d3[0] / tr_one_nn;
+    rz = d3[1] - c * d3[3];
+    zz = d3[2] - c * d3[0];
+    if (!(zz > 1e-6 * d3[2])) {
+      axpby(NLv, -c, tr_one, 1.0, cg_z);
+      double d2[2];
+      multidot(NLv, cg_z, {cg_r, cg_z}, d2, KL);
+      rz = d2[0]; zz = d2[1]; c = 0.0;
+    }
+  }
 
   // ------------------------------------------------------------------ unsplit (monolithic) solve
   // System (hdg_imex.py:602-620; hdg_implicit.py:153-185), gamma = a_ii dt (or dt):

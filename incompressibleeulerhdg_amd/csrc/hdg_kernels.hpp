@@ -488,9 +488,10 @@ __global__ __launch_bounds__(128) void k_trace_apply(Geo g, DevTables T, const d
 
 // edge-block Jacobi / Chebyshev update on the trace space:
 //   d = c1*d + c2 * Dinv r ;  x += d        (ASMStarPC with construct_dim=1: one block per facet)
+//   assign != 0:  x = d  (first step from a zero initial guess: x is not read)
 template <int K>
 __global__ __launch_bounds__(128) void k_trace_cheb(Geo g, DevTables T, const double* __restrict__ r, double* __restrict__ d,
-                                                     double* __restrict__ x, double c1, double c2) {
+                                                     double* __restrict__ x, double c1, double c2, int assign) {
   constexpr int NL = Dim<K>::NL;
   HDG_CORNER_PROLOGUE
 #pragma unroll
@@ -512,7 +513,7 @@ __global__ __launch_bounds__(128) void k_trace_cheb(Geo g, DevTables T, const do
       const long idx = ((long)t * NL + m) * g.G + o;
       const double dn = fma(c1, (c1 != 0.0 ? d[idx] : 0.0), c2 * z[m]);
       d[idx] = dn;
-      if (x) x[idx] += dn;
+      if (x) x[idx] = assign ? dn : x[idx] + dn;
     }
   }
 }
@@ -939,6 +940,25 @@ __global__ void k_lincomb(long N, LinComb lc, double* __restrict__ out) {
     out[idx] = acc;
   }
 }
+// conjugate-gradient updates of the trace solver in one pass each:
+//   x += alpha p ; r -= alpha Ap
+__global__ void k_cg_xr(long N, double alpha, const double* __restrict__ p, const double* __restrict__ Ap,
+                        double* __restrict__ x, double* __restrict__ r) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < N; idx += stride) {
+    x[idx] = fma(alpha, p[idx], x[idx]);
+    r[idx] = fma(-alpha, Ap[idx], r[idx]);
+  }
+}
+//   p = (z - c n) + beta p      (n: null-space vector; z - c n is the projected preconditioned residual)
+__global__ void k_cg_p(long N, const double* __restrict__ z, const double* __restrict__ nvec, double c, double beta,
+                       double* __restrict__ p) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < N; idx += stride) {
+    const double zp = fma(-c, nvec[idx], z[idx]);
+    p[idx] = (beta == 0.0) ? zp : fma(beta, p[idx], zp);
+  }
+}
 // y = a*x + b*y
 __global__ void k_axpby(long N, double a, const double* __restrict__ x, double b, double* __restrict__ y) {
   const long stride = (long)gridDim.x * blockDim.x;
@@ -952,7 +972,8 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
-// partial dots of w against nv vectors V[k] (k < nv <= MAXV): part[block*nv + k]; deterministic
+// partial dots of w against nv vectors V[k] (k < nv <= MAXV): part[block*nvo + k]; deterministic.
+// cross != 0 (nv >= 2, nv < MAXV): one more result, (V[0], V[1]), from the values already loaded; nvo = nv + cross
 #define HDG_DOT_BLOCK 256
 // entries outside the rows [lo, hi] of the (ghosted) row structure are skipped: every dot product
 // counts each OWNED entry exactly once across ranks (w_ == 0: no mask)
@@ -962,7 +983,7 @@ struct RowMask {
 template <int MAXV>
 __global__ __launch_bounds__(HDG_DOT_BLOCK) void k_multidot(long N, const double* __restrict__ w,
                                                              const double* const* __restrict__ V, int nv,
-                                                             double* __restrict__ part, RowMask mk) {
+                                                             double* __restrict__ part, RowMask mk, int cross) {
   __shared__ double sm[HDG_DOT_BLOCK / 64][MAXV];
   double acc[MAXV];
 #pragma unroll
@@ -974,23 +995,34 @@ __global__ __launch_bounds__(HDG_DOT_BLOCK) void k_multidot(long N, const double
       if (row < mk.lo || row > mk.hi) continue;
     }
     const double wv = w[idx];
+    if (cross) {
+      const double v0 = V[0][idx], v1 = V[1][idx];
+      acc[0] = fma(wv, v0, acc[0]);
+      acc[1] = fma(wv, v1, acc[1]);
+      acc[nv] = fma(v0, v1, acc[nv]);
 #pragma unroll
-    for (int k = 0; k < MAXV; k++)
-      if (k < nv) acc[k] = fma(wv, V[k][idx], acc[k]);
+      for (int k = 2; k < MAXV; k++)
+        if (k < nv) acc[k] = fma(wv, V[k][idx], acc[k]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < MAXV; k++)
+        if (k < nv) acc[k] = fma(wv, V[k][idx], acc[k]);
+    }
   }
+  const int nvo = nv + (cross ? 1 : 0);
   const int lane = threadIdx.x & 63, wv_ = threadIdx.x >> 6;
 #pragma unroll
   for (int k = 0; k < MAXV; k++) {
-    if (k < nv) {
+    if (k < nvo) {
       const double s = wave_sum(acc[k]);
       if (lane == 0) sm[wv_][k] = s;
     }
   }
   __syncthreads();
-  if (threadIdx.x < nv) {
+  if (threadIdx.x < nvo) {
     double s = 0.0;
     for (int w2 = 0; w2 < HDG_DOT_BLOCK / 64; w2++) s += sm[w2][threadIdx.x];
-    part[(long)blockIdx.x * nv + threadIdx.x] = s;
+    part[(long)blockIdx.x * nvo + threadIdx.x] = s;
   }
 }
 __global__ void k_reduce_parts(int nblocks, int nv, const double* __restrict__ part, double* __restrict__ res) {
