@@ -84,6 +84,7 @@ struct Engine {
   const double** d_gmV = nullptr;  // device array of the GMRES basis pointers
   double* d_part = nullptr;
   double* d_res = nullptr;
+  double* h_res = nullptr;  // pinned host mirror of d_res
   int dot_blocks = 0;
   // element block-Jacobi inverses per stage (depends on gamma = a_ii dt)
   std::vector<double*> dinv0, dinv1;
@@ -182,6 +183,7 @@ struct Engine {
   ~Engine() {
     if (vcycle_graph) (void)hipGraphExecDestroy(vcycle_graph);
     for (void* p : allocs) (void)hipFree(p);
+    if (h_res) (void)hipHostFree(h_res);
     if (stream) (void)hipStreamDestroy(stream);
     delete tab;
     delete comm;
@@ -249,6 +251,7 @@ struct Engine {
     dot_blocks = 1024;
     d_part = dalloc((long)dot_blocks * MAXV);
     d_res = dalloc(MAXV);
+    HIPCHECK(hipHostMalloc((void**)&h_res, sizeof(double) * MAXV));
     hQ_dev = dalloc(NQb); hP_dev = dalloc(NPb);
     hL_dev = dalloc(NLb);
     {
@@ -418,13 +421,15 @@ struct Engine {
     for (int off = 0; off < nv; off += MAXV) {
       int cnt = std::min(MAXV, nv - off);
       const int nout = cnt + (cross ? 1 : 0);
-      HIPCHECK(hipMemcpyAsync((void*)d_ptrs, V.data() + off, sizeof(double*) * cnt, hipMemcpyHostToDevice, stream));
+      VecList<MAXV> vl;
+      for (int q = 0; q < MAXV; q++) vl.p[q] = q < cnt ? V[off + q] : nullptr;
       int nb = std::min(dot_blocks, vec_blocks(n));
-      k_multidot<MAXV><<<nb, HDG_DOT_BLOCK, 0, stream>>>(n, w, d_ptrs, cnt, d_part, mask_for(kind), cross ? 1 : 0);
+      k_multidot<MAXV><<<nb, HDG_DOT_BLOCK, 0, stream>>>(n, w, vl, cnt, d_part, mask_for(kind), cross ? 1 : 0);
       k_reduce_parts<<<nout, 256, 0, stream>>>(nb, nout, d_part, d_res);
       comm->allreduce_sum(d_res, nout, stream);
-      HIPCHECK(hipMemcpyAsync(res + off, d_res, sizeof(double) * nout, hipMemcpyDeviceToHost, stream));
+      HIPCHECK(hipMemcpyAsync(h_res, d_res, sizeof(double) * nout, hipMemcpyDeviceToHost, stream));  // pinned
       HIPCHECK(hipStreamSynchronize(stream));
+      for (int q = 0; q < nout; q++) res[off + q] = h_res[q];
     }
   }
   double dot(long n, const double* a, const double* b, int kind) {
@@ -437,7 +442,9 @@ struct Engine {
     const double c0 = g.h / std::sqrt(2.0);  // integral of the mode-0 basis function = its "1" coefficient
     const double vol = 1.0;                  // domain_volume (common.py:72-73)
     int nb = std::min(dot_blocks, vec_blocks(g.Nc));
-    k_multidot<MAXV><<<nb, HDG_DOT_BLOCK, 0, stream>>>(g.Nc, p, d_ones_ptr, 1, d_part, mask_for(KC), 0);
+    VecList<MAXV> vl{};
+    vl.p[0] = ones_c;
+    k_multidot<MAXV><<<nb, HDG_DOT_BLOCK, 0, stream>>>(g.Nc, p, vl, 1, d_part, mask_for(KC), 0);
     k_reduce_parts<<<1, 256, 0, stream>>>(nb, 1, d_part, d_res);
     comm->allreduce_sum(d_res, 1, stream);
     k_shift_p<<<vec_blocks(g.Nc), 256, 0, stream>>>(g.Nc, p, d_res, c0 / vol, c0);

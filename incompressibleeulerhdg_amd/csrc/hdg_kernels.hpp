@@ -980,9 +980,14 @@ __device__ __forceinline__ double wave_sum(double v) {
 struct RowMask {
   int w_, nrows, lo, hi;
 };
+// vector list passed by value (kernel arguments): no host->device pointer upload per call
+template <int MAXV>
+struct VecList {
+  const double* p[MAXV];
+};
 template <int MAXV>
 __global__ __launch_bounds__(HDG_DOT_BLOCK) void k_multidot(long N, const double* __restrict__ w,
-                                                             const double* const* __restrict__ V, int nv,
+                                                             const VecList<MAXV> V, int nv,
                                                              double* __restrict__ part, RowMask mk, int cross) {
   __shared__ double sm[HDG_DOT_BLOCK / 64][MAXV];
   double acc[MAXV];
@@ -996,17 +1001,17 @@ __global__ __launch_bounds__(HDG_DOT_BLOCK) void k_multidot(long N, const double
     }
     const double wv = w[idx];
     if (cross) {
-      const double v0 = V[0][idx], v1 = V[1][idx];
+      const double v0 = V.p[0][idx], v1 = V.p[1][idx];
       acc[0] = fma(wv, v0, acc[0]);
       acc[1] = fma(wv, v1, acc[1]);
       acc[nv] = fma(v0, v1, acc[nv]);
 #pragma unroll
       for (int k = 2; k < MAXV; k++)
-        if (k < nv) acc[k] = fma(wv, V[k][idx], acc[k]);
+        if (k < nv) acc[k] = fma(wv, V.p[k][idx], acc[k]);
     } else {
 #pragma unroll
       for (int k = 0; k < MAXV; k++)
-        if (k < nv) acc[k] = fma(wv, V[k][idx], acc[k]);
+        if (k < nv) acc[k] = fma(wv, V.p[k][idx], acc[k]);
     }
   }
   const int nvo = nv + (cross ? 1 : 0);
