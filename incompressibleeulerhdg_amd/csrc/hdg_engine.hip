@@ -421,10 +421,17 @@ struct Engine {
     for (int off = 0; off < nv; off += MAXV) {
       int cnt = std::min(MAXV, nv - off);
       const int nout = cnt + (cross ? 1 : 0);
-      VecList<MAXV> vl;
-      for (int q = 0; q < MAXV; q++) vl.p[q] = q < cnt ? V[off + q] : nullptr;
       int nb = std::min(dot_blocks, vec_blocks(n));
-      k_multidot<MAXV><<<nb, HDG_DOT_BLOCK, 0, stream>>>(n, w, vl, cnt, d_part, mask_for(kind), cross ? 1 : 0);
+      if (nout <= 4) {
+        // the common case (CG / Chebyshev norms: 1-3 vectors): lean instantiation, 8 accumulator registers
+        VecList<4> vl;
+        for (int q = 0; q < 4; q++) vl.p[q] = q < cnt ? V[off + q] : nullptr;
+        k_multidot<4><<<nb, HDG_DOT_BLOCK, 0, stream>>>(n, w, vl, cnt, d_part, mask_for(kind), cross ? 1 : 0);
+      } else {
+        VecList<MAXV> vl;
+        for (int q = 0; q < MAXV; q++) vl.p[q] = q < cnt ? V[off + q] : nullptr;
+        k_multidot<MAXV><<<nb, HDG_DOT_BLOCK, 0, stream>>>(n, w, vl, cnt, d_part, mask_for(kind), cross ? 1 : 0);
+      }
       k_reduce_parts<<<nout, 256, 0, stream>>>(nb, nout, d_part, d_res);
       comm->allreduce_sum(d_res, nout, stream);
       HIPCHECK(hipMemcpyAsync(h_res, d_res, sizeof(double) * nout, hipMemcpyDeviceToHost, stream));  // pinned
@@ -442,9 +449,9 @@ struct Engine {
     const double c0 = g.h / std::sqrt(2.0);  // integral of the mode-0 basis function = its "1" coefficient
     const double vol = 1.0;                  // domain_volume (common.py:72-73)
     int nb = std::min(dot_blocks, vec_blocks(g.Nc));
-    VecList<MAXV> vl{};
+    VecList<4> vl{};
     vl.p[0] = ones_c;
-    k_multidot<MAXV><<<nb, HDG_DOT_BLOCK, 0, stream>>>(g.Nc, p, vl, 1, d_part, mask_for(KC), 0);
+    k_multidot<4><<<nb, HDG_DOT_BLOCK, 0, stream>>>(g.Nc, p, vl, 1, d_part, mask_for(KC), 0);
     k_reduce_parts<<<1, 256, 0, stream>>>(nb, 1, d_part, d_res);
     comm->allreduce_sum(d_res, 1, stream);
     k_shift_p<<<vec_blocks(g.Nc), 256, 0, stream>>>(g.Nc, p, d_res, c0 / vol, c0);

@@ -991,12 +991,15 @@ __global__ __launch_bounds__(HDG_DOT_BLOCK) void k_multidot(long N, const double
                                                              double* __restrict__ part, RowMask mk, int cross) {
   __shared__ double sm[HDG_DOT_BLOCK / 64][MAXV];
   double acc[MAXV];
+  double accx = 0.0;  // cross product (own register: a runtime index into acc[] would demote it to scratch)
 #pragma unroll
   for (int k = 0; k < MAXV; k++) acc[k] = 0.0;
   const long stride = (long)gridDim.x * blockDim.x;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < N; idx += stride) {
     if (mk.w_ > 0) {
-      const int row = (int)((idx / mk.w_) % mk.nrows);
+      // 32-bit arithmetic whenever the index fits (always, up to 2^31 entries): 64-bit division is ~4x dearer
+      const int row = (N <= 0x7fffffffL) ? (int)(((unsigned)idx / (unsigned)mk.w_) % (unsigned)mk.nrows)
+                                         : (int)((idx / mk.w_) % mk.nrows);
       if (row < mk.lo || row > mk.hi) continue;
     }
     const double wv = w[idx];
@@ -1004,7 +1007,7 @@ __global__ __launch_bounds__(HDG_DOT_BLOCK) void k_multidot(long N, const double
       const double v0 = V.p[0][idx], v1 = V.p[1][idx];
       acc[0] = fma(wv, v0, acc[0]);
       acc[1] = fma(wv, v1, acc[1]);
-      acc[nv] = fma(v0, v1, acc[nv]);
+      accx = fma(v0, v1, accx);
 #pragma unroll
       for (int k = 2; k < MAXV; k++)
         if (k < nv) acc[k] = fma(wv, V.p[k][idx], acc[k]);
@@ -1018,10 +1021,14 @@ __global__ __launch_bounds__(HDG_DOT_BLOCK) void k_multidot(long N, const double
   const int lane = threadIdx.x & 63, wv_ = threadIdx.x >> 6;
 #pragma unroll
   for (int k = 0; k < MAXV; k++) {
-    if (k < nvo) {
+    if (k < nv) {
       const double s = wave_sum(acc[k]);
       if (lane == 0) sm[wv_][k] = s;
     }
+  }
+  if (cross) {
+    const double s = wave_sum(accx);
+    if (lane == 0) sm[wv_][nv] = s;
   }
   __syncthreads();
   if (threadIdx.x < nvo) {
