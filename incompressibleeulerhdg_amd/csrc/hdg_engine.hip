@@ -87,7 +87,7 @@ struct Engine {
   double* h_res = nullptr;  // pinned host mirror of d_res
   int dot_blocks = 0;
   // element block-Jacobi inverses per stage (depends on gamma = a_ii dt)
-  std::vector<double*> dinv0, dinv1;
+  std::vector<double*> dinv0, dinv1, hybg0, hybg1;
   std::vector<double> dinv_gamma;
   // trace Chebyshev bounds
   double cheb_lmin = 0, cheb_lmax = 0;
@@ -258,7 +258,7 @@ struct Engine {
       long cap = std::max<long>(2L * NU * 2L * g.nx, 3L * NL * g.P);
       hb_slo = dalloc(cap); hb_shi = dalloc(cap); hb_rlo = dalloc(cap); hb_rhi = dalloc(cap);
     }
-    for (int i = 0; i < s; i++) { dinv0.push_back(nullptr); dinv1.push_back(nullptr); dinv_gamma.push_back(-1.0); }
+    for (int i = 0; i < s; i++) { dinv0.push_back(nullptr); dinv1.push_back(nullptr); hybg0.push_back(nullptr); hybg1.push_back(nullptr); dinv_gamma.push_back(-1.0); }
   }
 
   // ------------------------------------------------------------------ kernel dispatch on K
@@ -299,8 +299,8 @@ struct Engine {
     halo_Q(in);
     HDG_DISPATCH(k_edge_lift<KK, false, 1><<<cell_grid(), bs(), 0, stream>>>(g, dt, in, out, r, D0, D1, chd_, chx_, c1, c2));
   }
-  // hybrid two-level preconditioner in ONE kernel: out = Pi(in) + Dinv (in - Pi(in)), optionally fused with
-  // the Chebyshev step
+  // hybrid two-level preconditioner in ONE kernel: out = Pi(in) + Dinv (in - Pi(in)) = in + sum_e G_e d_e(in),
+  // optionally fused with the Chebyshev step; G0 / G1: tables (I - Dinv_s) Lift_e of the stage (ensure_dinv)
   void bdm_hybrid(const double* in, double* out, const double* D0, const double* D1, double* chd_ = nullptr,
                   double* chx_ = nullptr, double c1 = 0.0, double c2 = 0.0) {
     halo_Q(in);
@@ -511,6 +511,23 @@ struct Engine {
     if (!dinv0[idx]) { dinv0[idx] = dalloc((long)a.size()); dinv1[idx] = dalloc((long)b.size()); }
     HIPCHECK(hipMemcpyAsync(dinv0[idx], a.data(), sizeof(double) * a.size(), hipMemcpyHostToDevice, stream));
     HIPCHECK(hipMemcpyAsync(dinv1[idx], b.data(), sizeof(double) * b.size(), hipMemcpyHostToDevice, stream));
+    // hybrid preconditioner tables G_e = (I - Dinv_s) Lift_e, 3 blocks of 2nu x ne per shape (k_edge_lift<.,.,2>)
+    const int n2 = 2 * tab->nu, ne = tab->ne;
+    dvec G[2];
+    for (int sh = 0; sh < 2; sh++) {
+      const dvec& Di = sh == 0 ? a : b;
+      G[sh].assign((size_t)3 * n2 * ne, 0.0);
+      for (int e = 0; e < 3; e++)
+        for (int r = 0; r < n2; r++)
+          for (int q = 0; q < ne; q++) {
+            double acc = tab->Lift[sh][e][r * ne + q];
+            for (int m = 0; m < n2; m++) acc -= Di[(size_t)r * n2 + m] * tab->Lift[sh][e][m * ne + q];
+            G[sh][((size_t)e * n2 + r) * ne + q] = acc;
+          }
+    }
+    if (!hybg0[idx]) { hybg0[idx] = dalloc((long)G[0].size()); hybg1[idx] = dalloc((long)G[1].size()); }
+    HIPCHECK(hipMemcpyAsync(hybg0[idx], G[0].data(), sizeof(double) * G[0].size(), hipMemcpyHostToDevice, stream));
+    HIPCHECK(hipMemcpyAsync(hybg1[idx], G[1].data(), sizeof(double) * G[1].size(), hipMemcpyHostToDevice, stream));
     HIPCHECK(hipStreamSynchronize(stream));
     dinv_gamma[idx] = gamma;
   }
@@ -522,7 +539,7 @@ struct Engine {
       bdm_T(r, wQ3);
       bdm_plus_bj(wQ3, z, r, dinv0[didx], dinv1[didx]);
     } else {
-      bdm_hybrid(r, z, dinv0[didx], dinv1[didx]);
+      bdm_hybrid(r, z, hybg0[didx], hybg1[didx]);
     }
   }
   // z = M r fused with the Chebyshev step d = c1 d + c2 z, x += d (owned rows only: the ghost rows of x are
@@ -536,7 +553,7 @@ struct Engine {
       bdm_T(r, wQ3);
       bdm_plus_bj(wQ3, zout, r, dinv0[didx], dinv1[didx], d_, x_, c1, c2);
     } else {
-      bdm_hybrid(r, zout, dinv0[didx], dinv1[didx], d_, x_, c1, c2);
+      bdm_hybrid(r, zout, hybg0[didx], hybg1[didx], d_, x_, c1, c2);
     }
   }
   // solve (I - gamma F(Q*)) x = b with left-preconditioned GMRES(m); x holds the initial guess.
@@ -1401,7 +1418,7 @@ struct Engine {
         case 6:  // hybrid two-level preconditioner (one lift + block-Jacobi of the remainder) + Chebyshev step
           ensure_dinv(1 % s, 0.25 * cfg.dt);
           if (!chd) chd = dalloc(NQ);
-          bdm_hybrid(wQ2, nullptr, dinv0[1 % s], dinv1[1 % s], chd, wQ4, 0.5, 0.1);
+          bdm_hybrid(wQ2, nullptr, hybg0[1 % s], hybg1[1 % s], chd, wQ4, 0.5, 0.1);
           break;
         case 7: adv_apply(curQ, Qstar[0], wQ1, 0.25 * cfg.dt, wQ2); break;  // residual form b - A x
         default: throw std::string("unknown kernel id");

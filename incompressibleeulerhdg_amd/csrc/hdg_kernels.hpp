@@ -140,23 +140,35 @@ __device__ __forceinline__ void mv_acc_ld(const double* __restrict__ A, int LD, 
 //   with (In, Out) = (Lift^T, N^T) it is its transpose (used by the two-level preconditioner).
 // ------------------------------------------------------------------------------------------
 //   ADD_BJ = 1 (additive two-level preconditioner): result += Dinv_s * r_K  with a separate vector r.
-//   ADD_BJ = 2 (hybrid two-level preconditioner M = Pi + Dinv (I - Pi), one kernel): with y = Pi(in),
-//              result = y + Dinv_s * (in_K - y_K): the conforming part of the residual is kept as is, the
-//              non-conforming remainder goes through the element block-Jacobi.
+//   ADD_BJ = 2 (hybrid two-level preconditioner M = Pi + Dinv (I - Pi), one kernel): with Pi x = x + sum_e
+//              Lift_e d_e(x) this is  M x = x + sum_e G_e d_e(x),  G_e = (I - Dinv_s) Lift_e  (host tables per
+//              shape and stage, passed through Dinv0 / Dinv1 as 3 consecutive 2NU x NE blocks): the conforming
+//              part of the residual is kept, the non-conforming remainder goes through the element block-Jacobi,
+//              at the cost of the plain projection.
 //   Optional Chebyshev epilogue (chd != nullptr): with z the kernel's result,
 //   d = c1*d + c2*z ; x += d ; z itself is stored only if out != nullptr (needed for norm checks).
+// Register diet: the cell's own normal moments -N_e x are taken first, so that only ONE cell-sized array (y,
+// initialised with x) stays live while the neighbours are visited.
+#ifndef HDG_LIFT_WAVES
+#define HDG_LIFT_WAVES (K <= 2 && ADD_BJ != 1 ? 4 : 1)
+#endif
 template <int K, bool TRANSPOSE, int ADD_BJ>
-__global__ __launch_bounds__(128) void k_edge_lift(Geo g, DevTables T, const double* __restrict__ in,
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(HDG_LIFT_WAVES)))
+void k_edge_lift(Geo g, DevTables T, const double* __restrict__ in,
                                                     double* __restrict__ out, const double* __restrict__ r,
                                                     const double* __restrict__ Dinv0, const double* __restrict__ Dinv1,
                                                     double* __restrict__ chd, double* __restrict__ chx, double c1,
                                                     double c2) {
   constexpr int NU = Dim<K>::NU, NE = Dim<K>::NE, N2 = 2 * NU;
   HDG_CELL_PROLOGUE
-  double x[N2], y[N2];
-  load_cell<N2>(in, g.Nc, c, x);
+  double y[N2], down[3][NE];
+  load_cell<N2>(in, g.Nc, c, y);
 #pragma unroll
-  for (int n = 0; n < N2; n++) y[n] = x[n];
+  for (int e = 0; e < 3; e++) {
+#pragma unroll
+    for (int a = 0; a < NE; a++) down[e][a] = 0.0;
+    mv_acc<NE, N2>(TRANSPOSE ? T.LiftT[s][e] : T.N[s][e], y, down[e], -1.0);
+  }
   if (ADD_BJ == 1) {
     double rr[N2];
     load_cell<N2>(r, g.Nc, c, rr);
@@ -164,27 +176,18 @@ __global__ __launch_bounds__(128) void k_edge_lift(Geo g, DevTables T, const dou
   }
 #pragma unroll
   for (int e = 0; e < 3; e++) {
-    const double* __restrict__ Iown = TRANSPOSE ? T.LiftT[s][e] : T.N[s][e];
     const double* __restrict__ Inb = TRANSPOSE ? T.LiftT[1 - s][e] : T.N[1 - s][e];
-    const double* __restrict__ Out = TRANSPOSE ? T.Nt[s][e] : T.Lift[s][e];
-    double d[NE];
-#pragma unroll
-    for (int a = 0; a < NE; a++) d[a] = 0.0;
-    mv_acc<NE, N2>(Iown, x, d, -1.0);
+    const double* __restrict__ Out =
+        ADD_BJ == 2 ? (s == 0 ? Dinv0 : Dinv1) + e * N2 * NE : (TRANSPOSE ? T.Nt[s][e] : T.Lift[s][e]);
     long cn;
     if (nbr(s, e, i, j, g, cn)) {
       double xn[N2];
       load_cell<N2>(in, g.Nc, cn, xn);
-      mv_acc<NE, N2>(Inb, xn, d, 1.0);
+      mv_acc<NE, N2>(Inb, xn, down[e], 1.0);
 #pragma unroll
-      for (int a = 0; a < NE; a++) d[a] *= 0.5;
+      for (int a = 0; a < NE; a++) down[e][a] *= 0.5;
     }
-    mv_acc<N2, NE>(Out, d, y, 1.0);
-  }
-  if (ADD_BJ == 2) {
-#pragma unroll
-    for (int n = 0; n < N2; n++) x[n] -= y[n];  // non-conforming remainder (I - Pi) in
-    mv_acc<N2, N2>(s == 0 ? Dinv0 : Dinv1, x, y, 1.0);
+    mv_acc<N2, NE>(Out, down[e], y, 1.0);
   }
   if (out) store_cell<N2>(out, g.Nc, c, y);
   if (chd) {
@@ -206,8 +209,12 @@ __global__ __launch_bounds__(128) void k_edge_lift(Geo g, DevTables T, const dou
 //   ceil((3k+4)/2) Gauss points (the |Q*.n| integrand is not polynomial: SURVEY.md App. D.3).
 // ------------------------------------------------------------------------------------------
 //   Optional residual epilogue: with bsub != nullptr the kernel writes  bsub - (x - gamma F x).
+#ifndef HDG_ADV_WAVES
+#define HDG_ADV_WAVES 1
+#endif
 template <int K>
-__global__ __launch_bounds__(128) void k_adv_apply(Geo g, DevTables T, const double* __restrict__ xin,
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(HDG_ADV_WAVES)))
+void k_adv_apply(Geo g, DevTables T, const double* __restrict__ xin,
                                                     const double* __restrict__ qstar, double* __restrict__ out,
                                                     double gamma, double upwind, const double* __restrict__ bsub) {
   constexpr int NU = Dim<K>::NU, N2 = 2 * NU;
