@@ -149,8 +149,11 @@ __device__ __forceinline__ void mv_acc_ld(const double* __restrict__ A, int LD, 
 //   d = c1*d + c2*z ; x += d ; z itself is stored only if out != nullptr (needed for norm checks).
 // Register diet: the cell's own normal moments -N_e x are taken first, so that only ONE cell-sized array (y,
 // initialised with x) stays live while the neighbours are visited.
+// minimum waves/SIMD requested from the compiler; 1 = no constraint.  Measured at C3 (k = 2, hybrid + Chebyshev):
+// unconstrained 154 VGPRs / 3 waves / no scratch: 0.329 ms; forced 4 waves (128 VGPRs, 92 B/lane scratch, +0.55 GB
+// of HBM traffic per launch): 0.393 ms; forced 5 waves: 0.56 ms
 #ifndef HDG_LIFT_WAVES
-#define HDG_LIFT_WAVES (K <= 2 && ADD_BJ != 1 ? 4 : 1)
+#define HDG_LIFT_WAVES 1
 #endif
 template <int K, bool TRANSPOSE, int ADD_BJ>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(HDG_LIFT_WAVES)))
@@ -188,15 +191,41 @@ void k_edge_lift(Geo g, DevTables T, const double* __restrict__ in,
       for (int a = 0; a < NE; a++) down[e][a] *= 0.5;
     }
     mv_acc<N2, NE>(Out, down[e], y, 1.0);
+#ifdef HDG_LIFT_SCHED_BARRIER
+    // keep the next neighbour's loads behind this edge's arithmetic: the live set then fits 128 VGPRs
+    // (4 waves/SIMD) without spilling
+    __builtin_amdgcn_sched_barrier(0);
+#endif
   }
   if (out) store_cell<N2>(out, g.Nc, c, y);
   if (chd) {
+    // The c1 == 0 case (first Chebyshev step: d is not read) is decided ONCE, outside the element loop: with
+    // the test inside, every element became its own branch -> load -> wait -> store block, 2 N2 dependent
+    // memory round trips per wave.  Here each half issues its N2 loads back to back, then N2 stores.
+    const bool rd = (c1 != 0.0);
 #pragma unroll
-    for (int n = 0; n < N2; n++) {
-      const long idx = (long)n * g.Nc + c;
-      const double dn = (c1 != 0.0) ? fma(c1, chd[idx], c2 * y[n]) : c2 * y[n];
-      chd[idx] = dn;
-      chx[idx] += dn;
+    for (int half = 0; half < 2; half++) {
+      constexpr int H2 = N2 / 2;
+      double dd[H2], xx[H2];
+#pragma unroll
+      for (int n = 0; n < H2; n++) {
+        const long idx = (long)(half * H2 + n) * g.Nc + c;
+        xx[n] = chx[idx];
+      }
+      if (rd) {
+#pragma unroll
+        for (int n = 0; n < H2; n++) dd[n] = chd[(long)(half * H2 + n) * g.Nc + c];
+      } else {
+#pragma unroll
+        for (int n = 0; n < H2; n++) dd[n] = 0.0;
+      }
+#pragma unroll
+      for (int n = 0; n < H2; n++) {
+        const long idx = (long)(half * H2 + n) * g.Nc + c;
+        const double dn = rd ? fma(c1, dd[n], c2 * y[half * H2 + n]) : c2 * y[half * H2 + n];
+        chd[idx] = dn;
+        chx[idx] = xx[n] + dn;
+      }
     }
   }
 }
@@ -515,12 +544,28 @@ __global__ __launch_bounds__(128) void k_trace_cheb(Geo g, DevTables T, const do
     for (int m = 0; m < NL; m++) z[m] = 0.0;
     const double* __restrict__ Dm = T.trDinv[t][var];
     mv_acc_ld<NL, NL>(Dm, NL, rr, z, 1.0);
+    // loads first (the c1 == 0 / assign decisions are wave uniform and taken outside the element loop)
+    double dold[NL], xold[NL];
+    if (c1 != 0.0) {
+#pragma unroll
+      for (int m = 0; m < NL; m++) dold[m] = d[((long)t * NL + m) * g.G + o];
+    } else {
+#pragma unroll
+      for (int m = 0; m < NL; m++) dold[m] = 0.0;
+    }
+    if (x && !assign) {
+#pragma unroll
+      for (int m = 0; m < NL; m++) xold[m] = x[((long)t * NL + m) * g.G + o];
+    } else {
+#pragma unroll
+      for (int m = 0; m < NL; m++) xold[m] = 0.0;
+    }
 #pragma unroll
     for (int m = 0; m < NL; m++) {
       const long idx = ((long)t * NL + m) * g.G + o;
-      const double dn = fma(c1, (c1 != 0.0 ? d[idx] : 0.0), c2 * z[m]);
+      const double dn = fma(c1, dold[m], c2 * z[m]);
       d[idx] = dn;
-      if (x) x[idx] = assign ? dn : x[idx] + dn;
+      if (x) x[idx] = assign ? dn : xold[m] + dn;
     }
   }
 }
