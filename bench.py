@@ -188,13 +188,14 @@ def main():
             ("tentative", "pressure", "final_pressure", "pressure_reconstruction"), sums, cnt)}
         ntot = eng.n_total
         value = ntot * args.steps / elapsed / 1e6
-        # --- roofline of the dominant kernel.  The kernel with the largest share of the step (28 % in
-        # profiles/r01_h_kernel_stats_c3_hybrid.csv) is the tentative-velocity preconditioner fused with the
-        # Chebyshev update: k_edge_lift<K,false,2> (BDM lift Pi, element block-Jacobi of the non-conforming
-        # remainder, d = c1 d + c2 z, x += d in one pass).  Algorithmic bytes per launch: it reads 3 velocity
-        # vectors (residual, direction d, iterate x) and writes 2 (d, x), 8 B per entry (SURVEY.md section
-        # 8d); with the additive preconditioner (--tent-precond 1) the kernel is k_edge_lift<K,false,1>
-        # and reads one vector more.  Duration from HIP events on the engine's stream.
+        # --- roofline of the dominant kernel.  A Chebyshev iteration of the tentative-velocity solve is two
+        # launches that share ~55 % of the step (profiles/r01_i_kernel_stats_c3.csv: 28.6 % + 26.6 %):
+        #   k_adv_apply (residual form): t = b - (I - gamma F(Q*)) x; reads x, Q*, b and writes t: 4 vectors;
+        #   k_edge_lift<K,false,2> + Chebyshev step: z = t + sum_e G_e d_e(t) (BDM lift with the element
+        #     block-Jacobi folded into the lifting tables), d = c1 d + c2 z, x += d: reads t, d, x, writes d, x:
+        #     5 vectors (the additive preconditioner, --tent-precond 1, reads one more).
+        # 8 B per entry.  Whichever takes longer per launch is reported as the dominant
+        # kernel, the other under other_kernels.  Durations from HIP events on the engine's stream.
         NQ = eng.n_cells * 2 * eng.n_u  # this rank's strip: kernel timings below are per-rank launches
         NL = eng.n_edges * eng.n_l
         NP = eng.n_cells * eng.n_p
@@ -205,22 +206,29 @@ def main():
         ms_tr = eng.time_kernel(1, 50)
         ms_bs = eng.time_kernel(3, 20)
         lift_bytes = 8.0 * (5 if hybrid else 6) * NQ
+        adv_bytes = 8.0 * 4 * NQ
         lift_name = ("k_edge_lift<K,false,2> (BDM lift + block-Jacobi of the remainder + Chebyshev step)" if hybrid
                      else "k_edge_lift<K,false,1> (BDM lift + block-Jacobi + Chebyshev step)")
-        traffic = None
+        adv_name = "k_adv_apply<K> (advection operator, residual form b - (I - gamma F) x)"
+        pmc = {}
         try:  # HBM bytes per launch from the committed PMC passes (same workload, single rank only)
             tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
             if tj["workload"] == {"nx": nx, "degree": k} and world == 1 and hybrid:
-                traffic = tj["kernels"]["k_edge_lift<K,false,2>+cheb"]["hbm_bytes"]
+                pmc = {"lift": tj["kernels"]["k_edge_lift<K,false,2>+cheb"]["hbm_bytes"],
+                       "adv": tj["kernels"]["k_adv_apply(+residual)"]["hbm_bytes"]}
         except Exception:
-            traffic = None
+            pmc = {}
         gbs = lambda b, ms: b / (ms * 1e-3) / 1e9
-        roof = dict(bound="hbm", kernel=lift_name,
-                    achieved=gbs(lift_bytes, ms_lift), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=gbs(lift_bytes, ms_lift) / HBM_PEAK_GBS, traffic=traffic, algorithmic_bytes=lift_bytes,
-                    ms_per_launch=ms_lift,
+        cand = {"lift": (lift_name, lift_bytes, ms_lift), "adv": (adv_name, adv_bytes, ms_adv)}
+        dom = "adv" if ms_adv >= ms_lift else "lift"
+        oth = "lift" if dom == "adv" else "adv"
+        dname, dbytes, dms = cand[dom]
+        roof = dict(bound="hbm", kernel=dname, achieved=gbs(dbytes, dms), peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=gbs(dbytes, dms) / HBM_PEAK_GBS, traffic=pmc.get(dom), algorithmic_bytes=dbytes,
+                    ms_per_launch=dms,
                     other_kernels={
-                        "k_adv_apply (residual form)": dict(ms=ms_adv, GBs=gbs(8.0 * 4 * NQ, ms_adv)),
+                        cand[oth][0]: dict(ms=cand[oth][2], GBs=gbs(cand[oth][1], cand[oth][2]),
+                                           algorithmic_bytes=cand[oth][1], traffic=pmc.get(oth)),
                         "k_edge_lift<K,true,0>": dict(ms=ms_liftT, GBs=gbs(8.0 * 2 * NQ, ms_liftT)),
                         "k_trace_apply": dict(ms=ms_tr, GBs=gbs(8.0 * 2 * NL, ms_tr)),
                         "k_backsub": dict(ms=ms_bs, GBs=gbs(8.0 * (NL + 2 * NQ + 2 * NP), ms_bs)),
