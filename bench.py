@@ -205,6 +205,7 @@ def main():
         ms_liftT = eng.time_kernel(5, 20)
         ms_tr = eng.time_kernel(1, 50)
         ms_bs = eng.time_kernel(3, 20)
+        ms_triad = eng.time_kernel(8, 20)  # y = a x + b y on velocity vectors: the HBM rate this box actually delivers
         lift_bytes = 8.0 * (5 if hybrid else 6) * NQ
         adv_bytes = 8.0 * 4 * NQ
         lift_name = ("k_edge_lift<K,false,2> (BDM lift + block-Jacobi of the remainder + Chebyshev step)" if hybrid
@@ -225,7 +226,8 @@ def main():
         dname, dbytes, dms = cand[dom]
         roof = dict(bound="hbm", kernel=dname, achieved=gbs(dbytes, dms), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=gbs(dbytes, dms) / HBM_PEAK_GBS, traffic=pmc.get(dom), algorithmic_bytes=dbytes,
-                    ms_per_launch=dms,
+                    ms_per_launch=dms, stream_triad_GBs=gbs(8.0 * 3 * NQ, ms_triad),
+                    frac_of_triad=gbs(dbytes, dms) / gbs(8.0 * 3 * NQ, ms_triad),
                     other_kernels={
                         cand[oth][0]: dict(ms=cand[oth][2], GBs=gbs(cand[oth][1], cand[oth][2]),
                                            algorithmic_bytes=cand[oth][1], traffic=pmc.get(oth)),

@@ -171,7 +171,8 @@ int hdg_apply_weak_divergence(hdg_handle* h, const double* Q, int broken, double
  * kernel: 0 advection apply, 1 trace apply, 2 BDM projection, 3 back-substitution,
  *         4 BDM lift + block-Jacobi + Chebyshev step (fused; additive preconditioner), 5 transposed BDM lift,
  *         6 hybrid preconditioner (BDM lift + block-Jacobi of the remainder) + Chebyshev step (fused),
- *         7 advection apply in residual form  b - (I - gamma F) x */
+ *         7 advection apply in residual form  b - (I - gamma F) x,
+ *         8 stream triad y = a x + b y on two velocity-sized vectors (the box's achievable HBM rate) */
 int hdg_time_kernel(hdg_handle* h, int kernel, int reps, double* ms_per_launch);
 
 #ifdef __cplusplus

@@ -181,6 +181,9 @@ struct Engine {
     HIPCHECK(hipStreamSynchronize(stream));
   }
   ~Engine() {
+    if (std::getenv("HDG_DEBUG") && comm && comm->rank == 0)
+      fprintf(stderr, "[comm] halo exchanges: velocity %ld, pressure %ld, trace %ld; all-reduces %ld; all-gathers %ld\n",
+              n_halo[0], n_halo[1], n_halo[2], n_reduce, n_gather);
     if (vcycle_graph) (void)hipGraphExecDestroy(vcycle_graph);
     for (void* p : allocs) (void)hipFree(p);
     if (h_res) (void)hipHostFree(h_res);
@@ -275,15 +278,18 @@ struct Engine {
   // reads; kernels write owned rows only.  (Pure vector updates act on ghosts too, which keeps
   // consistent copies consistent.)
   bool halo_on = true;  // switched off while timing bare kernel launches (hdg_time_kernel is not collective)
+  long n_halo[3] = {0, 0, 0}, n_reduce = 0, n_gather = 0;  // communication census (HDG_DEBUG, printed at destruction)
   void halo_rows(double* v, long plane_stride, int row_len, int nplanes) {
     if (comm->size == 1 || !halo_on) return;
     const long n = (long)nplanes * row_len;
     const int nb = vec_blocks(n);
-    k_pack_rows<<<nb, 256, 0, stream>>>(v, plane_stride, row_len, nplanes, 1, hb_slo);
-    k_pack_rows<<<nb, 256, 0, stream>>>(v, plane_stride, row_len, nplanes, g.ny, hb_shi);
+    n_halo[row_len == g.P ? 2 : (nplanes == NP * 2 ? 1 : 0)]++;
+    // 3 launches per exchange: pack both rows, neighbour send/recv, unpack both rows
+    const int nbh = std::min(nb, 256);
+    k_pack_rows<<<dim3(nbh, 2), 256, 0, stream>>>(v, plane_stride, row_len, nplanes, 1, g.ny, hb_slo, hb_shi);
     comm->exchange(hb_slo, hb_rlo, hb_shi, hb_rhi, (size_t)n, stream);
-    if (comm->rank > 0) k_unpack_rows<<<nb, 256, 0, stream>>>(v, plane_stride, row_len, nplanes, 0, hb_rlo);
-    if (comm->rank < comm->size - 1) k_unpack_rows<<<nb, 256, 0, stream>>>(v, plane_stride, row_len, nplanes, g.ny + 1, hb_rhi);
+    k_unpack_rows<<<dim3(nbh, 2), 256, 0, stream>>>(v, plane_stride, row_len, nplanes, comm->rank > 0 ? 0 : -1,
+                                                    comm->rank < comm->size - 1 ? g.ny + 1 : -1, hb_rlo, hb_rhi);
   }
   void halo_Q(const double* v) { halo_rows(const_cast<double*>(v), (long)(g.ny + 2) * g.nx, g.nx, 2 * NU * 2); }
   void halo_P(const double* v) { halo_rows(const_cast<double*>(v), (long)(g.ny + 2) * g.nx, g.nx, NP * 2); }
@@ -331,6 +337,13 @@ struct Engine {
   void trace_apply(const double* lam, const double* base, double cb, double ct, double* out) {
     halo_L(lam);
     HDG_DISPATCH(k_trace_apply<KK><<<corner_grid(), bs(), 0, stream>>>(g, pdt(), lam, base, cb, ct, out));
+  }
+  // fused smoother step (k_trace_smooth): r = cb*base + ct*(-S) v, z = Dinv r, dn = c1 v + c2 z, optional outputs
+  void trace_smooth(const double* v, const double* base, double cb, double ct, double c1, double c2, double* r_out,
+                    double* d_out, double* x, bool xadd, double xv) {
+    halo_L(v);
+    HDG_DISPATCH(k_trace_smooth<KK><<<corner_grid(), bs(), 0, stream>>>(g, pdt(), v, base, cb, ct, c1, c2, r_out, d_out, x,
+                                                                       xadd ? 1 : 0, xv));
   }
   void trace_cheb(const double* r, double* d, double* x, double c1, double c2, bool assign = false) {
     HDG_DISPATCH(k_trace_cheb<KK><<<corner_grid(), bs(), 0, stream>>>(g, pdt(), r, d, x, c1, c2, assign ? 1 : 0));
@@ -434,6 +447,7 @@ struct Engine {
       }
       k_reduce_parts<<<nout, 256, 0, stream>>>(nb, nout, d_part, d_res);
       comm->allreduce_sum(d_res, nout, stream);
+      n_reduce++;
       HIPCHECK(hipMemcpyAsync(h_res, d_res, sizeof(double) * nout, hipMemcpyDeviceToHost, stream));  // pinned
       HIPCHECK(hipStreamSynchronize(stream));
       for (int q = 0; q < nout; q++) res[off + q] = h_res[q];
@@ -862,6 +876,19 @@ struct Engine {
     const double theta = 0.5 * (cheb_lmax + cheb_lmin), delta = 0.5 * (cheb_lmax - cheb_lmin);
     const double sigma1 = theta / delta;
     double rho = 1.0 / sigma1;
+    static const bool fuse = !std::getenv("HDG_TRACE_NO_FUSE");
+    if (its == 2 && fuse) {
+      // two Chebyshev steps in two launches: operator, edge block-Jacobi and update fused (k_trace_smooth)
+      const double rn = 1.0 / (2.0 * sigma1 - rho), c2_0 = 1.0 / theta, c1_1 = rn * rho, c2_1 = 2.0 * rn / delta;
+      if (zero_init) {
+        trace_cheb(b, ch_d, nullptr, 0.0, c2_0);                                       // d0 = Dinv b / theta
+        trace_smooth(ch_d, b, 1.0, -1.0, c1_1, c2_1, nullptr, nullptr, x, false, 1.0);  // x = d0 + d1
+      } else {
+        trace_smooth(x, b, 1.0, -1.0, 0.0, c2_0, ch_r, ch_d, nullptr, false, 0.0);      // r0 = b - T x, d0
+        trace_smooth(ch_d, ch_r, 1.0, -1.0, c1_1, c2_1, nullptr, nullptr, x, true, 1.0);  // x += d0 + d1
+      }
+      return;
+    }
     // zero initial guess: the first residual is b itself and the first step assigns x (no copy, no fill)
     const double* r0 = b;
     if (!zero_init) { trace_apply(x, b, 1.0, -1.0, ch_r); r0 = ch_r; }
@@ -969,6 +996,7 @@ struct Engine {
       // every rank contributes its (ny+1) vertex rows; owners' rows are copied into the global vector
       const long blk = (long)(g.ny + 1) * (g.nx + 1);
       comm->allgather(mg_b[0] + (long)g.joff * (g.nx + 1), mg_gather, (size_t)blk, stream);
+      n_gather++;
       for (int r = 0; r < comm->size; r++) {
         const long rows = g.ny + (r == comm->size - 1 ? 1 : 0);
         HIPCHECK(hipMemcpyAsync(mg_b[0] + (long)r * g.ny * (g.nx + 1), mg_gather + (long)r * blk,
@@ -1421,6 +1449,7 @@ struct Engine {
           bdm_hybrid(wQ2, nullptr, hybg0[1 % s], hybg1[1 % s], chd, wQ4, 0.5, 0.1);
           break;
         case 7: adv_apply(curQ, Qstar[0], wQ1, 0.25 * cfg.dt, wQ2); break;  // residual form b - A x
+        case 8: axpby(NQ, 0.5, wQ2, 0.25, wQ1); break;  // stream triad y = a x + b y on velocity vectors: 3 passes of 8 N_Q bytes
         default: throw std::string("unknown kernel id");
       }
     };

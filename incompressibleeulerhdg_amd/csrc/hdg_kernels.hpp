@@ -466,20 +466,17 @@ __device__ __forceinline__ void load_tr(const double* __restrict__ l, const Geo&
   for (int m = 0; m < NL; m++) v[m] = l[((long)t * NL + m) * g.G + off];
 }
 
-// K6  trace apply (condensed Schur operator of firedrake.SCPC, hdg_imex.py:128-135), SPD form:
-//   out = cb*base + ct * (-S) lam
+// (-S) lam at the three edges (H, V, D) attached to grid corner (i, j): sums over the <= 2 cells per edge.
+// own[] receives lam at those edges in local-edge order (H0, D0, V0) of cell L(i,j).
 template <int K>
-__global__ __launch_bounds__(128) void k_trace_apply(Geo g, DevTables T, const double* __restrict__ lam,
-                                                      const double* __restrict__ base, double cb, double ct,
-                                                      double* __restrict__ out) {
+__device__ __forceinline__ void trace_stencil(const Geo& g, const DevTables& T, const double* __restrict__ lam, long o, int i,
+                                              bool in_x, bool in_y, bool below, double* own, double* yH, double* yV,
+                                              double* yD) {
   constexpr int NL = Dim<K>::NL, NT = 3 * NL;
-  HDG_CORNER_PROLOGUE
-  double yH[NL], yV[NL], yD[NL];
 #pragma unroll
   for (int m = 0; m < NL; m++) yH[m] = yV[m] = yD[m] = 0.0;
   const double* __restrict__ SL = T.SK[0];
   const double* __restrict__ SU = T.SK[1];
-  double own[NT];  // (H0, D0, V0) in local-edge order e0,e1,e2 of L(i,j)
   if (in_x) load_tr<NL>(lam, g, 0, o, own); else { for (int m = 0; m < NL; m++) own[m] = 0.0; }
   if (in_x && in_y) load_tr<NL>(lam, g, 2, o, own + NL); else { for (int m = 0; m < NL; m++) own[NL + m] = 0.0; }
   if (in_y) load_tr<NL>(lam, g, 1, o, own + 2 * NL); else { for (int m = 0; m < NL; m++) own[2 * NL + m] = 0.0; }
@@ -511,14 +508,83 @@ __global__ __launch_bounds__(128) void k_trace_apply(Geo g, DevTables T, const d
     for (int m = 0; m < NL; m++) u[2 * NL + m] = own[2 * NL + m];
     mv_acc_ld<NL, NT>(SU + 2 * NL * NT, NT, u, yV, -1.0);
   }
+}
+
+// K6  trace apply (condensed Schur operator of firedrake.SCPC, hdg_imex.py:128-135), SPD form:
+//   out = cb*base + ct * (-S) lam
+template <int K>
+__global__ __launch_bounds__(128) void k_trace_apply(Geo g, DevTables T, const double* __restrict__ lam,
+                                                      const double* __restrict__ base, double cb, double ct,
+                                                      double* __restrict__ out) {
+  constexpr int NL = Dim<K>::NL, NT = 3 * NL;
+  HDG_CORNER_PROLOGUE
+  double yH[NL], yV[NL], yD[NL], own[NT];
+  trace_stencil<K>(g, T, lam, o, i, in_x, in_y, below, own, yH, yV, yD);
+  double bH[NL], bV[NL], bD[NL];
+  if (base) {
+#pragma unroll
+    for (int m = 0; m < NL; m++) {
+      bH[m] = cb * base[((long)0 * NL + m) * g.G + o];
+      bV[m] = cb * base[((long)1 * NL + m) * g.G + o];
+      bD[m] = cb * base[((long)2 * NL + m) * g.G + o];
+    }
+  } else {
+#pragma unroll
+    for (int m = 0; m < NL; m++) bH[m] = bV[m] = bD[m] = 0.0;
+  }
 #pragma unroll
   for (int m = 0; m < NL; m++) {
     const long iH = ((long)0 * NL + m) * g.G + o, iV = ((long)1 * NL + m) * g.G + o, iD = ((long)2 * NL + m) * g.G + o;
-    double bH = 0, bV = 0, bD = 0;
-    if (base) { bH = cb * base[iH]; bV = cb * base[iV]; bD = cb * base[iD]; }
-    out[iH] = in_x ? fma(ct, yH[m], bH) : 0.0;
-    out[iV] = in_y ? fma(ct, yV[m], bV) : 0.0;
-    out[iD] = (in_x && in_y) ? fma(ct, yD[m], bD) : 0.0;
+    out[iH] = in_x ? fma(ct, yH[m], bH[m]) : 0.0;
+    out[iV] = in_y ? fma(ct, yV[m], bV[m]) : 0.0;
+    out[iD] = (in_x && in_y) ? fma(ct, yD[m], bD[m]) : 0.0;
+  }
+}
+
+// Fused smoother step on the trace space (operator + edge block-Jacobi + Chebyshev update in one pass):
+//   r = cb*base + ct*(-S) v ;  z = Dinv r ;  dn = c1*v + c2*z     (v is the previous direction when c1 != 0)
+//   r_out <- r, d_out <- dn (each only if the pointer is given);
+//   x given:  x <- (xadd ? x : 0) + xv*v + dn
+// v is read through the stencil by neighbouring threads, so dn goes to a DIFFERENT buffer (d_out != v).
+// The two-step Chebyshev smoother of the trace preconditioner is then 2 launches and 5-8 vector passes
+// instead of 3-4 launches and 11-15 passes (Engine::cheb_smooth).
+template <int K>
+__global__ __launch_bounds__(128) void k_trace_smooth(Geo g, DevTables T, const double* __restrict__ v,
+                                                       const double* __restrict__ base, double cb, double ct, double c1,
+                                                       double c2, double* __restrict__ r_out, double* __restrict__ d_out,
+                                                       double* __restrict__ x, int xadd, double xv) {
+  constexpr int NL = Dim<K>::NL, NT = 3 * NL;
+  HDG_CORNER_PROLOGUE
+  double y[3][NL], own[NT];  // y[t]: t = 0 H, 1 V, 2 D  (plane order of the trace layout)
+  trace_stencil<K>(g, T, v, o, i, in_x, in_y, below, own, y[0], y[1], y[2]);
+  const bool valid[3] = {in_x, in_y, in_x && in_y};
+  const int ownoff[3] = {0, 2 * NL, NL};  // own[] is in local-edge order (H, D, V)
+  const int var[3] = {(g.joff + j == 0) ? 1 : (g.joff + j == g.nyg ? 2 : 0), (i == 0) ? 1 : (i == g.nx ? 2 : 0), 0};
+  double bb[3][NL], xo[3][NL];
+#pragma unroll
+  for (int t = 0; t < 3; t++)
+#pragma unroll
+    for (int m = 0; m < NL; m++) {
+      const long idx = ((long)t * NL + m) * g.G + o;
+      bb[t][m] = (base && valid[t]) ? cb * base[idx] : 0.0;
+      xo[t][m] = (x && xadd && valid[t]) ? x[idx] : 0.0;
+    }
+#pragma unroll
+  for (int t = 0; t < 3; t++) {
+    if (!valid[t]) continue;
+    double r[NL], z[NL];
+#pragma unroll
+    for (int m = 0; m < NL; m++) { r[m] = fma(ct, y[t][m], bb[t][m]); z[m] = 0.0; }
+    mv_acc_ld<NL, NL>(T.trDinv[t][var[t]], NL, r, z, 1.0);
+#pragma unroll
+    for (int m = 0; m < NL; m++) {
+      const long idx = ((long)t * NL + m) * g.G + o;
+      const double vo = own[ownoff[t] + m];
+      const double dn = fma(c1, vo, c2 * z[m]);
+      if (r_out) r_out[idx] = r[m];
+      if (d_out) d_out[idx] = dn;
+      if (x) x[idx] = xo[t][m] + fma(xv, vo, dn);
+    }
   }
 }
 
@@ -1509,8 +1575,11 @@ __global__ void k_trace_to_p1(Geo g, int NL, const double* __restrict__ l, doubl
 //   trace vectors: planes = 3 * NL,           row length P,   row stride P,  plane stride G
 // buf layout [plane][i]; `row` is the array row index (0 = ghost below, 1..ny owned, ny+1 ghost above)
 // ------------------------------------------------------------------------------------------
-__global__ void k_pack_rows(const double* __restrict__ v, long plane_stride, int row_len, int nplanes, int row,
-                            double* __restrict__ buf) {
+// blockIdx.y = 0 / 1: lower / upper message, so one launch packs (unpacks) both halo rows
+__global__ void k_pack_rows(const double* __restrict__ v, long plane_stride, int row_len, int nplanes, int row_lo,
+                            int row_hi, double* __restrict__ buf_lo, double* __restrict__ buf_hi) {
+  const int row = blockIdx.y == 0 ? row_lo : row_hi;
+  double* __restrict__ buf = blockIdx.y == 0 ? buf_lo : buf_hi;
   const long n = (long)nplanes * row_len;
   const long stride = (long)gridDim.x * blockDim.x;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += stride) {
@@ -1519,8 +1588,12 @@ __global__ void k_pack_rows(const double* __restrict__ v, long plane_stride, int
     buf[idx] = v[pl * plane_stride + (long)row * row_len + i];
   }
 }
-__global__ void k_unpack_rows(double* __restrict__ v, long plane_stride, int row_len, int nplanes, int row,
-                              const double* __restrict__ buf) {
+// a negative row = that neighbour does not exist
+__global__ void k_unpack_rows(double* __restrict__ v, long plane_stride, int row_len, int nplanes, int row_lo,
+                              int row_hi, const double* __restrict__ buf_lo, const double* __restrict__ buf_hi) {
+  const int row = blockIdx.y == 0 ? row_lo : row_hi;
+  if (row < 0) return;
+  const double* __restrict__ buf = blockIdx.y == 0 ? buf_lo : buf_hi;
   const long n = (long)nplanes * row_len;
   const long stride = (long)gridDim.x * blockDim.x;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += stride) {
