@@ -319,6 +319,17 @@ struct Engine {
   void adv_apply(const double* x, const double* qstar, double* out, double gamma, const double* bsub = nullptr) {
     halo_Q(x);
     const double up = cfg.flux_upwind ? 1.0 : 0.0;
+    // k = 3: two lanes per cell, one velocity component each (k_adv_apply2).  Measured at nx = 512, one-lane vs
+    // two-lane kernel: k=1 181 / 205 us (nx 1024), k=2 353 / 370 us (nx 1024), k=3 407 / 334 us, k=4 719 / 1488 us
+    // (254 VGPRs, still 1 wave/SIMD, twice the waves).  HDG_ADV_SPLIT=lo:hi overrides the degree range.
+    static const char* split_env = std::getenv("HDG_ADV_SPLIT");
+    int split_lo = 3, split_hi = 3;
+    if (split_env) std::sscanf(split_env, "%d:%d", &split_lo, &split_hi);
+    if (cfg.degree >= split_lo && cfg.degree <= split_hi) {
+      const int cpb = bs() / 2, nbx2 = (g.nx + cpb - 1) / cpb;
+      HDG_DISPATCH(k_adv_apply2<KK><<<dim3(8 * g.rows_xcd * 2 * nbx2), bs(), 0, stream>>>(g, dt, x, qstar, out, gamma, up, bsub));
+      return;
+    }
     HDG_DISPATCH(k_adv_apply<KK><<<cell_grid(), bs(), 0, stream>>>(g, dt, x, qstar, out, gamma, up, bsub));
   }
   void blockdiag(const double* D0, const double* D1, const double* r, const double* zin, double cz, double* out) {

@@ -335,6 +335,105 @@ void k_adv_apply(Geo g, DevTables T, const double* __restrict__ xin,
 }
 
 // ------------------------------------------------------------------------------------------
+// K3, two lanes per cell (used for k >= 3): lane parity = velocity component a.  Every table of this kernel
+// (cell / edge basis tabulations) is the same for both components, so the table operands stay wave uniform
+// (SGPR); only two quantities couple the components and cross the lane pair with one DPP swap each:
+// Q* at the quadrature points (each lane evaluates its own component) and the normal jump of the penalty.
+// Per lane: x_a, Q*_a, F_a, neighbour x_a = 4 NU doubles instead of 8 NU: 120 instead of 240+ VGPRs at
+// k = 3 (the one-lane kernel sits at the 256-VGPR cap with AGPR spills, 1 wave/SIMD).  Same arithmetic
+// per output entry as k_adv_apply, in the same order, except for the two pairwise sums.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double pair_swap(double v) { return __shfl_xor(v, 1, 64); }
+template <int K>
+__global__ __launch_bounds__(128) void k_adv_apply2(Geo g, DevTables T, const double* __restrict__ xin,
+                                                     const double* __restrict__ qstar, double* __restrict__ out,
+                                                     double gamma, double upwind, const double* __restrict__ bsub) {
+  constexpr int NU = Dim<K>::NU;
+  // cell prologue with blockDim.x / 2 cells per workgroup (same XCD-aware row walk as HDG_CELL_PROLOGUE)
+  const int cpb = blockDim.x >> 1, nbx2 = (g.nx + cpb - 1) / cpb;
+  const int xcd_ = blockIdx.x & 7, q_ = blockIdx.x >> 3;
+  const int jj_ = q_ / (2 * nbx2), rem_ = q_ - jj_ * 2 * nbx2;
+  const int s = rem_ / nbx2;
+  const int i = (rem_ - s * nbx2) * cpb + (threadIdx.x >> 1);
+  const int a = threadIdx.x & 1;  // velocity component of this lane
+  const int j = xcd_ * g.rows_xcd + jj_;
+  if (jj_ >= g.rows_xcd || j >= g.ny || i >= g.nx) return;  // both lanes of a pair leave together
+  const long c = ((long)s * (g.ny + 2) + (j + 1)) * g.nx + i;
+  const long cbase = (long)a * NU * g.Nc + c;
+  double x[NU], qs[NU], F[NU];
+#pragma unroll
+  for (int m = 0; m < NU; m++) { x[m] = xin[cbase + (long)m * g.Nc]; qs[m] = qstar[cbase + (long)m * g.Nc]; F[m] = 0.0; }
+  // ---- cell term:  F_a[m] -= w Phi[q,m] (Q*.grad) x_a
+  {
+    const double* __restrict__ Phi = T.cPhi[s];
+    const double* __restrict__ Gx = T.cGx[s];
+    const double* __restrict__ Gy = T.cGy[s];
+    const int nq = T.nqc;
+#pragma unroll 1
+    for (int q = 0; q < nq; q++) {
+      double qa = 0, dx_ = 0, dy_ = 0;
+#pragma unroll
+      for (int m = 0; m < NU; m++) {
+        qa = fma(Phi[q * NU + m], qs[m], qa);
+        dx_ = fma(Gx[q * NU + m], x[m], dx_);
+        dy_ = fma(Gy[q * NU + m], x[m], dy_);
+      }
+      const double qb = pair_swap(qa);
+      const double qx = a == 0 ? qa : qb, qy = a == 0 ? qb : qa;
+      const double av = -T.cw[q] * (qx * dx_ + qy * dy_);
+#pragma unroll
+      for (int m = 0; m < NU; m++) F[m] = fma(Phi[q * NU + m], av, F[m]);
+    }
+  }
+  // ---- facet terms
+#pragma unroll
+  for (int e = 0; e < 3; e++) {
+    long cn;
+    const bool has = nbr(s, e, i, j, g, cn);
+    double xn[NU];
+    if (has) {
+#pragma unroll
+      for (int m = 0; m < NU; m++) xn[m] = xin[((long)a * NU + m) * g.Nc + cn];
+    } else {
+#pragma unroll
+      for (int m = 0; m < NU; m++) xn[m] = 0.0;
+    }
+    const double* __restrict__ Po = T.ePhi[s][e];
+    const double* __restrict__ Pn = T.ePhi[1 - s][e];
+    const double na = a == 0 ? T.enx[e] : T.eny[e], sg = T.sig[s][e];
+    const double pen = T.alpha / T.elen[e];
+    const int nq = T.nqe;
+#pragma unroll 1
+    for (int q = 0; q < nq; q++) {
+      double oa = 0, ba = 0, qna = 0;
+#pragma unroll
+      for (int m = 0; m < NU; m++) {
+        const double po = Po[q * NU + m];
+        oa = fma(po, x[m], oa);
+        ba = fma(Pn[q * NU + m], xn[m], ba);
+        qna = fma(po, na * qs[m], qna);
+      }
+      const double qn = qna + pair_swap(qna);  // Q*.n: both components
+      const double w = T.ew[e][q];
+      const double cf = has ? w * (0.5 * sg * qn - upwind * fabs(qn)) : 0.0;
+      const double ja = oa - ba;
+      const double jna = ja * na;
+      const double jn = (jna + pair_swap(jna)) * pen * w;  // normal jump: both components
+      const double va = cf * ja - jn * na;
+#pragma unroll
+      for (int m = 0; m < NU; m++) F[m] = fma(Po[q * NU + m], va, F[m]);
+    }
+  }
+  if (bsub) {
+#pragma unroll
+    for (int m = 0; m < NU; m++) out[cbase + (long)m * g.Nc] = bsub[cbase + (long)m * g.Nc] - fma(-gamma, F[m], x[m]);
+  } else {
+#pragma unroll
+    for (int m = 0; m < NU; m++) out[cbase + (long)m * g.Nc] = fma(-gamma, F[m], x[m]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // K4  element block-Jacobi:  out = cz * zin + Dinv_s * r      (Dinv: 2NU x 2NU per shape)
 // ------------------------------------------------------------------------------------------
 template <int K>

@@ -138,3 +138,17 @@ def test_trace_reconstruction_and_shift(hip_lib, k, nx):
     _, p1, l1 = e.get_field(1)
     ps, ls = d.shift_pressure(p, lam_r)
     assert _relerr(p1, ps) < RTOL and _relerr(l1, ls) < RTOL
+
+
+def test_two_lane_advection_kernel_all_degrees(hip_lib):
+    """k_adv_apply2 (one velocity component per lane, used for k = 3 by default) against the oracle for every
+    degree: HDG_ADV_SPLIT=1:4 routes k = 1..4 through it (the switch is read once per process -> worker)."""
+    import os
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "adv_split_worker.py")], env=dict(os.environ, HDG_ADV_SPLIT="1:4"),
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert r.returncode == 0, r.stdout.decode()[-2000:]
+    assert r.stdout.decode().count("e-") == 8
