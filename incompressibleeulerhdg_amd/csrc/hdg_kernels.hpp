@@ -191,11 +191,6 @@ void k_edge_lift(Geo g, DevTables T, const double* __restrict__ in,
       for (int a = 0; a < NE; a++) down[e][a] *= 0.5;
     }
     mv_acc<N2, NE>(Out, down[e], y, 1.0);
-#ifdef HDG_LIFT_SCHED_BARRIER
-    // keep the next neighbour's loads behind this edge's arithmetic: the live set then fits 128 VGPRs
-    // (4 waves/SIMD) without spilling
-    __builtin_amdgcn_sched_barrier(0);
-#endif
   }
   if (out) store_cell<N2>(out, g.Nc, c, y);
   if (chd) {
