@@ -251,7 +251,7 @@ struct Engine {
     HIPCHECK(hipMalloc(&p, sizeof(double*) * (std::max(m, MAXV) + 2)));
     allocs.push_back(p);
     d_ptrs = (const double**)p;
-    dot_blocks = 1024;
+    dot_blocks = 2048;
     d_part = dalloc((long)dot_blocks * MAXV);
     d_res = dalloc(MAXV);
     HIPCHECK(hipHostMalloc((void**)&h_res, sizeof(double) * MAXV));

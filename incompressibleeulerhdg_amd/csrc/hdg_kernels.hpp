@@ -1207,26 +1207,47 @@ __global__ __launch_bounds__(HDG_DOT_BLOCK) void k_multidot(long N, const double
 #pragma unroll
   for (int k = 0; k < MAXV; k++) acc[k] = 0.0;
   const long stride = (long)gridDim.x * blockDim.x;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < N; idx += stride) {
-    if (mk.w_ > 0) {
-      // 32-bit arithmetic whenever the index fits (always, up to 2^31 entries): 64-bit division is ~4x dearer
-      const int row = (N <= 0x7fffffffL) ? (int)(((unsigned)idx / (unsigned)mk.w_) % (unsigned)mk.nrows)
-                                         : (int)((idx / mk.w_) % mk.nrows);
-      if (row < mk.lo || row > mk.hi) continue;
-    }
-    const double wv = w[idx];
-    if (cross) {
-      const double v0 = V.p[0][idx], v1 = V.p[1][idx];
-      acc[0] = fma(wv, v0, acc[0]);
-      acc[1] = fma(wv, v1, acc[1]);
-      accx = fma(v0, v1, accx);
+  // U independent elements per trip (lean instantiation only): all their loads are issued before the first FMA.
+  // Masked-out rows and the tail are handled by a 0/1 factor on w instead of a branch (every index read is a
+  // valid one: ghost rows exist, the tail is clamped), so the loads of a trip never wait for a predicate.
+  constexpr int U = MAXV <= 4 ? 4 : 1;
+  const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  for (long base = tid; base < N; base += U * stride) {
+    double wv[U], vv[U][MAXV];
 #pragma unroll
-      for (int k = 2; k < MAXV; k++)
-        if (k < nv) acc[k] = fma(wv, V.p[k][idx], acc[k]);
-    } else {
+    for (int u = 0; u < U; u++) {
+      const long idx0 = base + u * stride;
+      const bool inb = idx0 < N;
+      const long idx = inb ? idx0 : tid;
+      double mf = inb ? 1.0 : 0.0;
+      if (mk.w_ > 0) {
+        // 32-bit arithmetic whenever the index fits (always, up to 2^31 entries): 64-bit division is ~4x dearer
+        const int row = (N <= 0x7fffffffL) ? (int)(((unsigned)idx / (unsigned)mk.w_) % (unsigned)mk.nrows)
+                                           : (int)((idx / mk.w_) % mk.nrows);
+        if (row < mk.lo || row > mk.hi) mf = 0.0;
+      }
+      wv[u] = w[idx] * mf;
+#pragma unroll
+      for (int k = 0; k < MAXV; k++) vv[u][k] = (k < nv) ? V.p[k][idx] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
 #pragma unroll
       for (int k = 0; k < MAXV; k++)
-        if (k < nv) acc[k] = fma(wv, V.p[k][idx], acc[k]);
+        if (k < nv) acc[k] = fma(wv[u], vv[u][k], acc[k]);
+    }
+    if (cross) {
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const long idx0 = base + u * stride;
+        double mf = idx0 < N ? 1.0 : 0.0;
+        if (mk.w_ > 0 && idx0 < N) {
+          const int row = (N <= 0x7fffffffL) ? (int)(((unsigned)idx0 / (unsigned)mk.w_) % (unsigned)mk.nrows)
+                                             : (int)((idx0 / mk.w_) % mk.nrows);
+          if (row < mk.lo || row > mk.hi) mf = 0.0;
+        }
+        accx = fma(mf * vv[u][0], vv[u][1], accx);
+      }
     }
   }
   const int nvo = nv + (cross ? 1 : 0);
