@@ -58,7 +58,7 @@ def _assemble(parts, k, nx):
     return Q, p, lam
 
 
-@pytest.mark.parametrize("nranks,k,nx", [(2, 1, 8), (2, 2, 8), (4, 1, 8), (3, 2, 6)])
+@pytest.mark.parametrize("nranks,k,nx", [(2, 1, 8), (2, 2, 8), (4, 1, 8), (3, 2, 6), (2, 3, 4), (2, 2, 96)])
 def test_strip_partition_matches_single_rank(hip_lib, tmp_path, nranks, k, nx):
     from incompressibleeulerhdg_amd import _lib
     from incompressibleeulerhdg_amd.mesh import UnitSquareMesh
@@ -79,7 +79,11 @@ def test_strip_partition_matches_single_rank(hip_lib, tmp_path, nranks, k, nx):
     for d in parts[1:]:
         assert abs(float(d["eq"]) - float(parts[0]["eq"])) < 1e-13 and np.allclose(d["its"], parts[0]["its"])
     s1, c1 = ts._engine.iteration_stats()
-    assert np.all(np.abs(parts[0]["its"] - s1 / np.maximum(c1, 1)) <= 1.0)
+    its1 = s1 / np.maximum(c1, 1)
+    # condensed CG: same counts up to reduction order.  Tentative velocity: the Chebyshev iteration is driven by
+    # Ritz estimates (they move with the reduction order) and checks convergence every 4th iteration only
+    assert np.all(np.abs(parts[0]["its"][1:] - its1[1:]) <= 1.0)
+    assert abs(parts[0]["its"][0] - its1[0]) <= max(4.0, 0.25 * its1[0])
 
 
 def test_strip_partition_unsplit(hip_lib, tmp_path):
