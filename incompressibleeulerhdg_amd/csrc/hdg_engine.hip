@@ -85,6 +85,9 @@ struct Engine {
   double* d_part = nullptr;
   double* d_res = nullptr;
   double* h_res = nullptr;  // pinned host mirror of d_res
+  double* d_cgs = nullptr;  // device-resident CG scalars (k_cg_alpha / k_cg_beta)
+  double* h_cgs = nullptr;  // pinned snapshot of d_cgs for the lagged convergence check
+  hipEvent_t cg_ev = nullptr;
   int dot_blocks = 0;
   // element block-Jacobi inverses per stage (depends on gamma = a_ii dt)
   std::vector<double*> dinv0, dinv1, hybg0, hybg1;
@@ -187,6 +190,8 @@ struct Engine {
     if (vcycle_graph) (void)hipGraphExecDestroy(vcycle_graph);
     for (void* p : allocs) (void)hipFree(p);
     if (h_res) (void)hipHostFree(h_res);
+    if (h_cgs) (void)hipHostFree(h_cgs);
+    if (cg_ev) (void)hipEventDestroy(cg_ev);
     if (stream) (void)hipStreamDestroy(stream);
     delete tab;
     delete comm;
@@ -255,6 +260,9 @@ struct Engine {
     d_part = dalloc((long)dot_blocks * MAXV);
     d_res = dalloc(MAXV);
     HIPCHECK(hipHostMalloc((void**)&h_res, sizeof(double) * MAXV));
+    d_cgs = dalloc(8);
+    HIPCHECK(hipHostMalloc((void**)&h_cgs, sizeof(double) * 8));
+    HIPCHECK(hipEventCreateWithFlags(&cg_ev, hipEventDisableTiming));
     hQ_dev = dalloc(NQb); hP_dev = dalloc(NPb);
     hL_dev = dalloc(NLb);
     {
@@ -439,8 +447,10 @@ struct Engine {
   }
   // dots of w against nv vectors over the OWNED entries, summed over ranks (host result); one sync
   // cross: res[nv] additionally receives (V[0], V[1]) from the same pass (nv >= 2, single chunk)
+  // res == nullptr: the results stay in d_res on the device (single chunk), no host copy, no synchronisation
   void multidot(long n, const double* w, const std::vector<const double*>& V, double* res, int kind, bool cross = false) {
     int nv = (int)V.size();
+    if (!res && nv > MAXV) throw std::string("multidot: device-resident result needs a single chunk");
     if (cross && (nv < 2 || nv >= MAXV)) throw std::string("multidot: cross product needs 2 <= nv < MAXV");
     for (int off = 0; off < nv; off += MAXV) {
       int cnt = std::min(MAXV, nv - off);
@@ -459,6 +469,7 @@ struct Engine {
       k_reduce_parts<<<nout, 256, 0, stream>>>(nb, nout, d_part, d_res);
       comm->allreduce_sum(d_res, nout, stream);
       n_reduce++;
+      if (!res) continue;
       HIPCHECK(hipMemcpyAsync(h_res, d_res, sizeof(double) * nout, hipMemcpyDeviceToHost, stream));  // pinned
       HIPCHECK(hipStreamSynchronize(stream));
       for (int q = 0; q < nout; q++) res[off + q] = h_res[q];
@@ -1024,7 +1035,8 @@ struct Engine {
       trace_cheb(r, ch_d, z, 0.0, 1.0);
       return;
     }
-    cheb_smooth(r, z, true, 2);
+    static const int nsm = std::getenv("HDG_TRACE_SMOOTH_ITS") ? std::atoi(std::getenv("HDG_TRACE_SMOOTH_ITS")) : 2;
+    cheb_smooth(r, z, true, nsm);
     trace_apply(z, r, 1.0, -1.0, wL2);
     halo_L(wL2);
     k_trace_to_p1<<<corner_grid(), bs(), 0, stream>>>(g, NL, wL2, mg_b[0], dt.elen[0], dt.elen[2], dt.elen[1]);
@@ -1041,7 +1053,7 @@ struct Engine {
     }
     run_vcycle();
     k_p1_to_trace<<<corner_grid(), bs(), 0, stream>>>(g, NL, mg_x[0], z, 1.0, dt.elen[0], dt.elen[2], dt.elen[1]);
-    cheb_smooth(r, z, false, 2);
+    cheb_smooth(r, z, false, nsm);
   }
   void setup_trace_solver() {
     // null-space vector
@@ -1089,8 +1101,9 @@ struct Engine {
       lam = std::sqrt(dot(NLv, cg_z, cg_z, KL));
       copy(cg_p, cg_z, NLv);
     }
+    static const double flo = std::getenv("HDG_TRACE_CHEB_LO") ? std::atof(std::getenv("HDG_TRACE_CHEB_LO")) : 0.1;
     psets[idx].lmax = 1.1 * lam;
-    psets[idx].lmin = 0.1 * lam;
+    psets[idx].lmin = flo * lam;
     cur_pset = saved;
   }
   // operator set for a stabilisation parameter tau' (created on first use)
@@ -1114,9 +1127,70 @@ struct Engine {
   }
   // preconditioned CG on (-S) x = b from the initial guess in x; returns iterations.
   // Convergence on the preconditioned residual norm relative to its initial value (hdg_imex.py:136-137).
+  // Same iteration with the scalars kept on the device: alpha, beta and the projection coefficient are produced
+  // by one-thread kernels from the reduced dot products and read by the vector kernels, so the host never waits
+  // inside an iteration.  Convergence is checked ONE launch group late: the next operator application and its
+  // p.Ap reduction are queued first (they modify no state), then the host reads the snapshot of (z',z') taken
+  // after the preconditioner -- by then it has long arrived.  2 blocking syncs per iteration become 0.
+  int trace_cg_dev(double* b, double* x, double rtol, int maxit, bool strict) {
+    project_const(b);
+    trace_apply(x, b, 1.0, -1.0, cg_r);  // r = b - T x
+    trace_precond(cg_r, cg_z);
+    if (tr_one_nn < 0) tr_one_nn = dot(NLv, tr_one, tr_one, KL);
+    const int nvb = vec_blocks(NLv);
+    HIPCHECK(hipMemsetAsync(d_cgs, 0, sizeof(double) * 8, stream));
+    auto dots_and_snapshot = [&](int first) {
+      multidot(NLv, cg_z, {tr_one, cg_r, cg_z}, nullptr, KL, true);  // (z,n), (z,r), (z,z), (n,r) -> d_res
+      k_cg_beta<<<1, 1, 0, stream>>>(d_res, d_cgs, tr_one_nn, first);
+      HIPCHECK(hipMemcpyAsync(h_cgs, d_cgs, sizeof(double) * 8, hipMemcpyDeviceToHost, stream));
+      HIPCHECK(hipEventRecord(cg_ev, stream));
+    };
+    // (z',z') of the snapshot; on heavy cancellation (z almost parallel to the null vector) it is re-evaluated
+    // with the projection applied explicitly (cg_z still holds the z of the snapshot)
+    auto snapshot_norm2 = [&](bool direction_pending) {
+      HIPCHECK(hipEventSynchronize(cg_ev));
+      if (h_cgs[6] == 1.0) throw NotConverged{"trace CG: breakdown (p.Ap <= 0)"};
+      double zz = h_cgs[4];
+      if (h_cgs[6] == 2.0) {
+        axpby(NLv, -h_cgs[3], tr_one, 1.0, cg_z);
+        zz = dot(NLv, cg_z, cg_z, KL);
+        HIPCHECK(hipMemsetAsync(d_cgs + 6, 0, sizeof(double), stream));
+        // the direction update that consumes this z has not been queued yet: it must not project a second time
+        if (direction_pending) HIPCHECK(hipMemsetAsync(d_cgs + 3, 0, sizeof(double), stream));
+      }
+      if (!(zz == zz)) throw NotConverged{"trace CG: NaN residual"};
+      return zz;
+    };
+    dots_and_snapshot(1);
+    const double norm0 = std::sqrt(std::max(snapshot_norm2(true), 0.0));
+    if (norm0 == 0.0) return 0;
+    k_cg_p_dev<<<nvb, 256, 0, stream>>>(NLv, cg_z, tr_one, d_cgs, cg_p);
+    int its = 0;
+    while (true) {
+      trace_apply(cg_p, nullptr, 0.0, 1.0, cg_Ap);
+      multidot(NLv, cg_p, {cg_Ap}, nullptr, KL);
+      k_cg_alpha<<<1, 1, 0, stream>>>(d_res, d_cgs);
+      if (its > 0) {  // lagged check of the iterate x_its (the kernels queued above do not touch it)
+        const double nrm = std::sqrt(std::max(snapshot_norm2(false), 0.0));
+        if (std::getenv("HDG_DEBUG_CG")) fprintf(stderr, "[cg] it %d |z|/|z0| %.3e  c %.3e rz %.3e\n", its, nrm / norm0, h_cgs[3], h_cgs[0]);
+        if (nrm <= rtol * norm0) return its;
+        if (its >= maxit) {
+          if (strict) throw NotConverged{"trace CG reached max iterations"};
+          return its;
+        }
+      }
+      k_cg_xr_dev<<<nvb, 256, 0, stream>>>(NLv, d_cgs, cg_p, cg_Ap, x, cg_r);
+      trace_precond(cg_r, cg_z);
+      dots_and_snapshot(0);
+      its++;
+      k_cg_p_dev<<<nvb, 256, 0, stream>>>(NLv, cg_z, tr_one, d_cgs, cg_p);
+    }
+  }
   int trace_cg(double* b, double* x, double rtol = -1.0, int maxit = -1, bool strict = true) {
     if (rtol < 0) rtol = cfg.trace_rtol;
     if (maxit < 0) maxit = cfg.trace_maxit;
+    static const bool host_scalars = std::getenv("HDG_CG_HOST_SCALARS") != nullptr;
+    if (!host_scalars) return trace_cg_dev(b, x, rtol, maxit, strict);
     project_const(b);
     trace_apply(x, b, 1.0, -1.0, cg_r);  // r = b - T x
     trace_precond(cg_r, cg_z);

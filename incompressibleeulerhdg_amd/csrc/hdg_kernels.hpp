@@ -1171,6 +1171,45 @@ __global__ void k_cg_p(long N, const double* __restrict__ z, const double* __res
     p[idx] = (beta == 0.0) ? zp : fma(beta, p[idx], zp);
   }
 }
+// Device-resident scalars of the trace CG (no host round trip for alpha / beta / projection coefficient):
+//   sc[0] rz, sc[1] alpha, sc[2] beta, sc[3] c, sc[4] (z',z'), sc[5] p.Ap, sc[6] flag (1 breakdown, 2 cancellation),
+//   sc[7] (z,z) before the projection
+__global__ void k_cg_alpha(const double* __restrict__ res, double* __restrict__ sc) {
+  const double pAp = res[0];
+  sc[5] = pAp;
+  if (!(pAp > 0.0)) sc[6] = 1.0;
+  sc[1] = sc[0] / pAp;
+}
+// res = (z,n), (z,r), (z,z), (n,r);  nn = (n,n)
+__global__ void k_cg_beta(const double* __restrict__ res, double* __restrict__ sc, double nn, int first) {
+  const double c = res[0] / nn;
+  const double rzn = res[1] - c * res[3];
+  const double zz = res[2] - c * res[0];
+  if (!(zz > 1e-6 * res[2])) sc[6] = 2.0;
+  sc[3] = c;
+  sc[4] = zz;
+  sc[7] = res[2];
+  sc[2] = first ? 0.0 : rzn / sc[0];
+  sc[0] = rzn;
+}
+__global__ void k_cg_xr_dev(long N, const double* __restrict__ sc, const double* __restrict__ p, const double* __restrict__ Ap,
+                            double* __restrict__ x, double* __restrict__ r) {
+  const double alpha = sc[1];
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < N; idx += stride) {
+    x[idx] = fma(alpha, p[idx], x[idx]);
+    r[idx] = fma(-alpha, Ap[idx], r[idx]);
+  }
+}
+__global__ void k_cg_p_dev(long N, const double* __restrict__ z, const double* __restrict__ nvec, const double* __restrict__ sc,
+                           double* __restrict__ p) {
+  const double c = sc[3], beta = sc[2];
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < N; idx += stride) {
+    const double zp = fma(-c, nvec[idx], z[idx]);
+    p[idx] = (beta == 0.0) ? zp : fma(beta, p[idx], zp);
+  }
+}
 // y = a*x + b*y
 __global__ void k_axpby(long N, double a, const double* __restrict__ x, double b, double* __restrict__ y) {
   const long stride = (long)gridDim.x * blockDim.x;
