@@ -32,6 +32,11 @@
 
 namespace hdg {
 
+// diagnostics switches, read once per process: HDG_DEBUG (solver decisions, communication census),
+// HDG_DEBUG_CG (per-iteration residuals of the trace CG)
+static bool debug_on() { static const bool v = std::getenv("HDG_DEBUG") != nullptr; return v; }
+static bool debug_cg() { static const bool v = std::getenv("HDG_DEBUG_CG") != nullptr; return v; }
+
 struct HipError {
   std::string msg;
 };
@@ -184,7 +189,7 @@ struct Engine {
     HIPCHECK(hipStreamSynchronize(stream));
   }
   ~Engine() {
-    if (std::getenv("HDG_DEBUG") && comm && comm->rank == 0)
+    if (debug_on() && comm && comm->rank == 0)
       fprintf(stderr, "[comm] halo exchanges: velocity %ld, pressure %ld, trace %ld; all-reduces %ld; all-gathers %ld\n",
               n_halo[0], n_halo[1], n_halo[2], n_reduce, n_gather);
     if (vcycle_graph) (void)hipGraphExecDestroy(vcycle_graph);
@@ -802,7 +807,7 @@ struct Engine {
       lo *= f_lo; hi *= f_hi;
       if (ch_lmin[didx] > 0) { lo = std::min(lo, ch_lmin[didx]); hi = std::max(hi, ch_lmax[didx]); }
       ch_lmin[didx] = lo; ch_lmax[didx] = hi;
-      if (std::getenv("HDG_DEBUG")) {
+      if (debug_on()) {
         fprintf(stderr, "[cheb] stage %d ritz:", didx);
         for (auto v : ritz) fprintf(stderr, " %.3f%+.3fi", v.real(), v.imag());
         fprintf(stderr, "  -> interval [%.3f, %.3f], after GMRES cycle residual %.2e of %.2e\n", lo, hi, beta, beta0);
@@ -838,7 +843,7 @@ struct Engine {
     // needs 100-160 and is as fast or faster in wall time (tools/robustness_sweep.py) and has no parameters.
     static const int cheb_max_expected = std::getenv("HDG_CHEB_MAX_EXPECTED") ? std::atoi(std::getenv("HDG_CHEB_MAX_EXPECTED")) : 64;
     if (expected > cheb_max_expected || (!estimate && ch_slow[didx])) {
-      if (std::getenv("HDG_DEBUG")) fprintf(stderr, "[cheb] stage %d: %d iterations predicted on [%.3f, %.3f] -> GMRES\n", didx, expected, lo, hi);
+      if (debug_on()) fprintf(stderr, "[cheb] stage %d: %d iterations predicted on [%.3f, %.3f] -> GMRES\n", didx, expected, lo, hi);
       return its + gmres(qstar, gamma, didx, b, x, rtol, cfg.tent_maxit, true, nullptr, 0, nullptr, nullptr, beta0);
     }
     if (estimate) {
@@ -864,7 +869,7 @@ struct Engine {
       if (check) {
         double nz = std::sqrt(dot(NQ, z, z, KC));
         if (!(nz == nz)) throw NotConverged{"Chebyshev: NaN residual"};
-        if (std::getenv("HDG_DEBUG")) fprintf(stderr, "[cheb]   k=%d  |Mr|/|Mr0| = %.3e\n", k, nz / beta0);
+        if (debug_on()) fprintf(stderr, "[cheb]   k=%d  |Mr|/|Mr0| = %.3e\n", k, nz / beta0);
         if (nz <= rtol * beta0) {
           // z belongs to the iterate BEFORE the step just taken; that iterate had converged, and the
           // extra Chebyshev step only reduces the error further
@@ -885,7 +890,7 @@ struct Engine {
           } else {
             ch_slow[didx] = true;  // right interval, slow iteration: GMRES until the periodic re-estimate
           }
-          if (std::getenv("HDG_DEBUG"))
+          if (debug_on())
             fprintf(stderr, "[cheb]   falling back to GMRES at k=%d (%s; |Mr| %.2e, best %.2e)\n", k,
                     growing ? "growing" : "stalled", nz, last);
           return its + gmres(qstar, gamma, didx, b, x, rtol, cfg.tent_maxit, true, nullptr, 0, nullptr, nullptr, beta0);
@@ -1172,7 +1177,7 @@ struct Engine {
       k_cg_alpha<<<1, 1, 0, stream>>>(d_res, d_cgs);
       if (its > 0) {  // lagged check of the iterate x_its (the kernels queued above do not touch it)
         const double nrm = std::sqrt(std::max(snapshot_norm2(false), 0.0));
-        if (std::getenv("HDG_DEBUG_CG")) fprintf(stderr, "[cg] it %d |z|/|z0| %.3e  c %.3e rz %.3e\n", its, nrm / norm0, h_cgs[3], h_cgs[0]);
+        if (debug_cg()) fprintf(stderr, "[cg] it %d |z|/|z0| %.3e  c %.3e rz %.3e\n", its, nrm / norm0, h_cgs[3], h_cgs[0]);
         if (nrm <= rtol * norm0) return its;
         if (its >= maxit) {
           if (strict) throw NotConverged{"trace CG reached max iterations"};
@@ -1213,7 +1218,7 @@ struct Engine {
       cg_dots(rz_new, zz, c);
       its++;
       double nrm = std::sqrt(zz);
-      if (std::getenv("HDG_DEBUG_CG")) fprintf(stderr, "[cg] it %d |z|/|z0| %.3e  c %.3e rz %.3e pAp %.3e\n", its, nrm / norm0, c, rz_new, pAp);
+      if (debug_cg()) fprintf(stderr, "[cg] it %d |z|/|z0| %.3e  c %.3e rz %.3e pAp %.3e\n", its, nrm / norm0, c, rz_new, pAp);
       if (nrm <= rtol * norm0) return its;
       if (its >= maxit) {
         if (strict) throw NotConverged{"trace CG reached max iterations"};
