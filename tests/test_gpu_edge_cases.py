@@ -157,3 +157,26 @@ def test_fused_vcycle_kernels_are_bitwise_equal_to_the_per_level_launches(hip_li
         for name in ("Q", "p", "lam", "its"):
             assert np.array_equal(res["fused"][name], res["unfused"][name]), (nx, name)
             assert np.array_equal(res["fused"][name], res["plain"][name]), (nx, name)
+
+
+def test_alternative_trace_solver_paths_agree(hip_lib, tmp_path):
+    """The fused smoother step (k_trace_smooth) and the device-resident CG scalars are re-schedulings of the same
+    algorithm (different rounding order only): switching either off must give the same fields to well below the
+    solver tolerance and the same CG iteration counts."""
+    import os
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    res = {}
+    for tag, extra in (("default", {}), ("unfused_smoother", {"HDG_TRACE_NO_FUSE": "1"}),
+                       ("host_scalars", {"HDG_CG_HOST_SCALARS": "1"})):
+        out = str(tmp_path / f"{tag}.npz")
+        r = subprocess.run([sys.executable, os.path.join(here, "mp_strip_worker.py"), "0", "1", "unused", "2", "48", "2", out],
+                           env=dict(os.environ, **extra), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+        assert r.returncode == 0, r.stdout.decode()[-2000:]
+        res[tag] = np.load(out)
+    for tag in ("unfused_smoother", "host_scalars"):
+        for name in ("Q", "p", "lam"):
+            assert _rel(res[tag][name], res["default"][name]) < 1e-9, (tag, name)
+        assert np.all(np.abs(res[tag]["its"][1:] - res["default"]["its"][1:]) <= 1.0), tag
