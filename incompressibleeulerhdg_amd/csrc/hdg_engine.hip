@@ -180,6 +180,10 @@ struct Engine {
     g_all.nyc = g.ny + 1;
     g_all.rows_xcdc = (g_all.nyc + 7) / 8;
     NQ = 2L * NU * g.Nc; NPv = (long)NP * g.Nc; NLv = 3L * NL * g.G;
+    // cell kernels address a vector with 32-bit byte offsets (buffer loads, hdg_kernels.hpp: CellBuf)
+    if (NQ * 8L >= (1L << 32))
+      throw std::string("mesh too large for one GPU: a velocity vector must stay below 4 GiB (32-bit buffer offsets); "
+                        "use more ranks");
     NQb = 2L * NU * 2L * g.nx * g.ny; NPb = (long)NP * 2L * g.nx * g.ny;
     NLb = n_edges() * NL;
     tab = new Tables(K, g.h, c.tau, c.alpha_penalty, c.equispaced_nodes);

@@ -99,15 +99,39 @@ __device__ __forceinline__ long cidx(const Geo& g, int s, int j, int i) {
   return ((long)s * (g.ny + 2) + (j + 1)) * g.nx + i;
 }
 
+// Addressing of cell vectors v[n*Nc + c]: buffer loads / stores with the vector's base in a scalar resource
+// descriptor, the dof-plane offset n*Nc*8 in a scalar register and ONE 32-bit lane offset c*8 shared by all
+// planes.  With plain pointers the compiler materialises a 64-bit address per access in a VGPR pair (two
+// registers per outstanding load; `global_load ... v[a:b], off` throughout the ISA), which is what pushed the
+// element kernels to their register limits.  Offsets are 32 bit: a vector must stay below 4 GiB (checked on
+// the host at engine construction).
+typedef unsigned int hdg_u32x2 __attribute__((ext_vector_type(2)));
+struct CellBuf {
+  __amdgpu_buffer_rsrc_t r;
+  __device__ __forceinline__ explicit CellBuf(const double* p)
+      : r(__builtin_amdgcn_make_buffer_rsrc((void*)p, 0, 0xFFFFFFFF, 0x00020000)) {}
+  // plane offset in bytes (wave uniform), lane offset in bytes
+  __device__ __forceinline__ double ld(unsigned plane_b, unsigned lane_b) const {
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, lane_b, plane_b, 0));
+  }
+  __device__ __forceinline__ void st(unsigned plane_b, unsigned lane_b, double x) const {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(hdg_u32x2, x), r, lane_b, plane_b, 0);
+  }
+};
+__device__ __forceinline__ unsigned plane_bytes(int n, long Nc) { return (unsigned)((unsigned long)n * (unsigned long)Nc * 8ul); }
 template <int N>
 __device__ __forceinline__ void load_cell(const double* __restrict__ v, long Nc, long c, double (&x)[N]) {
+  const CellBuf B(v);
+  const unsigned lane_b = (unsigned)c * 8u;
 #pragma unroll
-  for (int n = 0; n < N; n++) x[n] = v[(long)n * Nc + c];
+  for (int n = 0; n < N; n++) x[n] = B.ld(plane_bytes(n, Nc), lane_b);
 }
 template <int N>
 __device__ __forceinline__ void store_cell(double* __restrict__ v, long Nc, long c, const double (&x)[N]) {
+  const CellBuf B(v);
+  const unsigned lane_b = (unsigned)c * 8u;
 #pragma unroll
-  for (int n = 0; n < N; n++) v[(long)n * Nc + c] = x[n];
+  for (int n = 0; n < N; n++) B.st(plane_bytes(n, Nc), lane_b, x[n]);
 }
 
 // y[r] += sc * sum_c A[r*NC + c] x[c]   (A wave-uniform -> scalar loads)
@@ -198,28 +222,26 @@ void k_edge_lift(Geo g, DevTables T, const double* __restrict__ in,
     // the test inside, every element became its own branch -> load -> wait -> store block, 2 N2 dependent
     // memory round trips per wave.  Here each half issues its N2 loads back to back, then N2 stores.
     const bool rd = (c1 != 0.0);
+    const CellBuf Bd(chd), Bx(chx);
+    const unsigned lane_b = (unsigned)c * 8u;
 #pragma unroll
     for (int half = 0; half < 2; half++) {
       constexpr int H2 = N2 / 2;
       double dd[H2], xx[H2];
 #pragma unroll
-      for (int n = 0; n < H2; n++) {
-        const long idx = (long)(half * H2 + n) * g.Nc + c;
-        xx[n] = chx[idx];
-      }
+      for (int n = 0; n < H2; n++) xx[n] = Bx.ld(plane_bytes(half * H2 + n, g.Nc), lane_b);
       if (rd) {
 #pragma unroll
-        for (int n = 0; n < H2; n++) dd[n] = chd[(long)(half * H2 + n) * g.Nc + c];
+        for (int n = 0; n < H2; n++) dd[n] = Bd.ld(plane_bytes(half * H2 + n, g.Nc), lane_b);
       } else {
 #pragma unroll
         for (int n = 0; n < H2; n++) dd[n] = 0.0;
       }
 #pragma unroll
       for (int n = 0; n < H2; n++) {
-        const long idx = (long)(half * H2 + n) * g.Nc + c;
         const double dn = rd ? fma(c1, dd[n], c2 * y[half * H2 + n]) : c2 * y[half * H2 + n];
-        chd[idx] = dn;
-        chx[idx] = xx[n] + dn;
+        Bd.st(plane_bytes(half * H2 + n, g.Nc), lane_b, dn);
+        Bx.st(plane_bytes(half * H2 + n, g.Nc), lane_b, xx[n] + dn);
       }
     }
   }
@@ -321,12 +343,15 @@ void k_adv_apply(Geo g, DevTables T, const double* __restrict__ xin,
     }
   }
   if (bsub) {
+    double bb[N2];
+    load_cell<N2>(bsub, g.Nc, c, bb);
 #pragma unroll
-    for (int n = 0; n < N2; n++) out[(long)n * g.Nc + c] = bsub[(long)n * g.Nc + c] - fma(-gamma, F[n], x[n]);
+    for (int n = 0; n < N2; n++) F[n] = bb[n] - fma(-gamma, F[n], x[n]);
   } else {
 #pragma unroll
-    for (int n = 0; n < N2; n++) out[(long)n * g.Nc + c] = fma(-gamma, F[n], x[n]);
+    for (int n = 0; n < N2; n++) F[n] = fma(-gamma, F[n], x[n]);
   }
+  store_cell<N2>(out, g.Nc, c, F);
 }
 
 // ------------------------------------------------------------------------------------------
