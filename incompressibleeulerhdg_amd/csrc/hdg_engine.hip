@@ -776,6 +776,7 @@ struct Engine {
   std::vector<double> ch_lmin, ch_lmax;
   std::vector<long> ch_count;
   std::vector<double> ch_widen;
+  std::vector<int> ch_last;   // iterations of the last converged Chebyshev solve of the stage (check schedule)
   std::vector<char> ch_slow;  // the last Chebyshev solve of the stage was slow: GMRES until the next re-estimate
   double* chd = nullptr;
   int cheb_gmres(const double* qstar, double gamma, int didx, const double* b, double* x) {
@@ -785,6 +786,7 @@ struct Engine {
     if ((int)ch_count.size() < s + 1) ch_count.assign(s + 1, 0);
     if ((int)ch_widen.size() < s + 1) ch_widen.assign(s + 1, 1.0);
     if ((int)ch_slow.size() < s + 1) ch_slow.assign(s + 1, 0);
+    if ((int)ch_last.size() < s + 1) ch_last.assign(s + 1, 0);
     std::vector<std::complex<double>> ritz;
     double beta0 = 0.0, beta = 0.0, lo, hi;
     int its = 0;
@@ -857,13 +859,18 @@ struct Engine {
       // z = M(b - A x) of the unchanged iterate is already in wQ1 (= z) from the norm evaluation above
       k_cheb_update<<<nvb, 256, 0, stream>>>(NQ, chd, z, x, 0.0, 1.0 / theta);
     }
+    const int ch_head = its;  // iterations of the opening GMRES cycle (0 without an estimate)
     int k = 1;
     its++;
     double last = beta, stall_ref = beta;
     int stall_checks = 0;
     while (true) {
-      // the norm of z_k = M(b - A x_k) is checked every 4th iteration: only then is z written out
-      const bool check = (k % 4 == 0);
+      // The norm of z_k = M(b - A x_k) is only evaluated at check points (z is written out only then: a check
+      // costs a vector store, a dot product and a host sync, ~1/4 of an iteration).  With the Chebyshev count
+      // of the previous solve of this stage known: every 8th iteration up to 4 before it (enough to catch
+      // growth), every 2nd from there on; without history every 4th.
+      const int kfine = ch_last[didx] > 0 ? std::max(4, (ch_last[didx] - ch_head - 4) & ~1) : 0;
+      const bool check = kfine > 0 ? (k < kfine ? (k % 8 == 0) : ((k - kfine) % 2 == 0)) : (k % 4 == 0);
       const double rn = 1.0 / (2.0 * sigma - rho);
       adv_apply(x, qstar, t, gamma, b);
       tent_precond_cheb(didx, t, check ? z : nullptr, chd, x, rn * rho, 2.0 * rn / delta);
@@ -878,6 +885,7 @@ struct Engine {
           // z belongs to the iterate BEFORE the step just taken; that iterate had converged, and the
           // extra Chebyshev step only reduces the error further
           ch_slow[didx] = its > cheb_max_expected + cheb_max_expected / 2;  // the prediction was optimistic
+          ch_last[didx] = its;
           return its;
         }
         // Guards.  Growth (an eigenvalue outside the ellipse of convergence): finish with GMRES and estimate
