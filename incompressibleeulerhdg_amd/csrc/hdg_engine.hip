@@ -90,6 +90,7 @@ struct Engine {
   double* d_part = nullptr;
   double* d_res = nullptr;
   double* h_res = nullptr;  // pinned host mirror of d_res
+  double* cell_ss = nullptr;  // |z_K|^2 per cell (Chebyshev convergence checks)
   double* d_cgs = nullptr;  // device-resident CG scalars (k_cg_alpha / k_cg_beta)
   double* h_cgs = nullptr;  // pinned snapshot of d_cgs for the lagged convergence check
   hipEvent_t cg_ev = nullptr;
@@ -250,6 +251,7 @@ struct Engine {
     cg_r = dalloc(NLv); cg_z = dalloc(NLv); cg_p = dalloc(NLv); cg_Ap = dalloc(NLv);
     ch_d = dalloc(NLv); ch_r = dalloc(NLv); tr_one = dalloc(NLv);
     ones_c = dalloc(g.Nc);
+    cell_ss = dalloc(g.Nc);
     k_fill<<<vec_blocks(g.Nc), 256, 0, stream>>>(g.Nc, ones_c, 1.0);
     d_ones_ptr = upload_ptrs({ones_c});
     int m = std::max(1, cfg.gmres_restart);
@@ -314,24 +316,24 @@ struct Engine {
 
   void bdm(const double* in, double* out) {
     halo_Q(in);
-    HDG_DISPATCH(k_edge_lift<KK, false, 0><<<cell_grid(), bs(), 0, stream>>>(g, dt, in, out, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, 0.0));
+    HDG_DISPATCH(k_edge_lift<KK, false, 0><<<cell_grid(), bs(), 0, stream>>>(g, dt, in, out, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, 0.0, nullptr));
   }
   // out = Pi(in) + Dinv r   (second half of the two-level preconditioner, block-Jacobi fused in)
   void bdm_plus_bj(const double* in, double* out, const double* r, const double* D0, const double* D1,
                    double* chd_ = nullptr, double* chx_ = nullptr, double c1 = 0.0, double c2 = 0.0) {
     halo_Q(in);
-    HDG_DISPATCH(k_edge_lift<KK, false, 1><<<cell_grid(), bs(), 0, stream>>>(g, dt, in, out, r, D0, D1, chd_, chx_, c1, c2));
+    HDG_DISPATCH(k_edge_lift<KK, false, 1><<<cell_grid(), bs(), 0, stream>>>(g, dt, in, out, r, D0, D1, chd_, chx_, c1, c2, nullptr));
   }
   // hybrid two-level preconditioner in ONE kernel: out = Pi(in) + Dinv (in - Pi(in)) = in + sum_e G_e d_e(in),
   // optionally fused with the Chebyshev step; G0 / G1: tables (I - Dinv_s) Lift_e of the stage (ensure_dinv)
   void bdm_hybrid(const double* in, double* out, const double* D0, const double* D1, double* chd_ = nullptr,
-                  double* chx_ = nullptr, double c1 = 0.0, double c2 = 0.0) {
+                  double* chx_ = nullptr, double c1 = 0.0, double c2 = 0.0, double* ss = nullptr) {
     halo_Q(in);
-    HDG_DISPATCH(k_edge_lift<KK, false, 2><<<cell_grid(), bs(), 0, stream>>>(g, dt, in, out, nullptr, D0, D1, chd_, chx_, c1, c2));
+    HDG_DISPATCH(k_edge_lift<KK, false, 2><<<cell_grid(), bs(), 0, stream>>>(g, dt, in, out, nullptr, D0, D1, chd_, chx_, c1, c2, ss));
   }
   void bdm_T(const double* in, double* out) {
     halo_Q(in);
-    HDG_DISPATCH(k_edge_lift<KK, true, 0><<<cell_grid(), bs(), 0, stream>>>(g, dt, in, out, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, 0.0));
+    HDG_DISPATCH(k_edge_lift<KK, true, 0><<<cell_grid(), bs(), 0, stream>>>(g, dt, in, out, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, 0.0, nullptr));
   }
   void adv_apply(const double* x, const double* qstar, double* out, double gamma, const double* bsub = nullptr) {
     halo_Q(x);
@@ -589,7 +591,9 @@ struct Engine {
   }
   // z = M r fused with the Chebyshev step d = c1 d + c2 z, x += d (owned rows only: the ghost rows of x are
   // refreshed by the next operator application); z is written to `zout` only when it is needed
-  void tent_precond_cheb(int didx, const double* r, double* zout, double* d_, double* x_, double c1, double c2) {
+  // cell_norm (hybrid preconditioner only): instead of z the kernel writes |z_K|^2 per cell into cell_ss
+  void tent_precond_cheb(int didx, const double* r, double* zout, double* d_, double* x_, double c1, double c2,
+                         bool cell_norm = false) {
     if (cfg.tent_precond == 0) {
       blockdiag(dinv0[didx], dinv1[didx], r, nullptr, 0.0, wQ4);
       if (zout) copy(zout, wQ4, NQ);
@@ -598,7 +602,7 @@ struct Engine {
       bdm_T(r, wQ3);
       bdm_plus_bj(wQ3, zout, r, dinv0[didx], dinv1[didx], d_, x_, c1, c2);
     } else {
-      bdm_hybrid(r, zout, hybg0[didx], hybg1[didx], d_, x_, c1, c2);
+      bdm_hybrid(r, zout, hybg0[didx], hybg1[didx], d_, x_, c1, c2, cell_norm ? cell_ss : nullptr);
     }
   }
   // solve (I - gamma F(Q*)) x = b with left-preconditioned GMRES(m); x holds the initial guess.
@@ -870,15 +874,18 @@ struct Engine {
       // of the previous solve of this stage known: every 8th iteration up to 4 before it (enough to catch
       // growth), every 2nd from there on; without history every 4th.
       const int kfine = ch_last[didx] > 0 ? std::max(4, (ch_last[didx] - ch_head - 4) & ~1) : 0;
-      const bool check = kfine > 0 ? (k < kfine ? (k % 8 == 0) : ((k - kfine) % 2 == 0)) : (k % 4 == 0);
+      static const int fine_step = std::getenv("HDG_CHEB_FINE_STEP") ? std::atoi(std::getenv("HDG_CHEB_FINE_STEP")) : 2;
+      const bool check = kfine > 0 ? (k < kfine ? (k % 8 == 0) : ((k - kfine) % fine_step == 0)) : (k % 4 == 0);
       const double rn = 1.0 / (2.0 * sigma - rho);
       adv_apply(x, qstar, t, gamma, b);
-      tent_precond_cheb(didx, t, check ? z : nullptr, chd, x, rn * rho, 2.0 * rn / delta);
+      // hybrid preconditioner: the lift kernel emits |z_K|^2 per cell (N_c doubles) instead of z (N_Q doubles)
+      const bool cell_norm = check && cfg.tent_precond == 2;
+      tent_precond_cheb(didx, t, (check && !cell_norm) ? z : nullptr, chd, x, rn * rho, 2.0 * rn / delta, cell_norm);
       rho = rn;
       k++;
       its++;
       if (check) {
-        double nz = std::sqrt(dot(NQ, z, z, KC));
+        double nz = cell_norm ? std::sqrt(dot(g.Nc, cell_ss, ones_c, KC)) : std::sqrt(dot(NQ, z, z, KC));
         if (!(nz == nz)) throw NotConverged{"Chebyshev: NaN residual"};
         if (debug_on()) fprintf(stderr, "[cheb]   k=%d  |Mr|/|Mr0| = %.3e\n", k, nz / beta0);
         if (nz <= rtol * beta0) {

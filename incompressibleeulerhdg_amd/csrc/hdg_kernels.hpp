@@ -170,7 +170,7 @@ __device__ __forceinline__ void mv_acc_ld(const double* __restrict__ A, int LD, 
 //              part of the residual is kept, the non-conforming remainder goes through the element block-Jacobi,
 //              at the cost of the plain projection.
 //   Optional Chebyshev epilogue (chd != nullptr): with z the kernel's result,
-//   d = c1*d + c2*z ; x += d ; z itself is stored only if out != nullptr (needed for norm checks).
+//   d = c1*d + c2*z ; x += d ; z itself is stored only if out != nullptr; cell_ss != nullptr: per-cell |z_K|^2.
 // Register diet: the cell's own normal moments -N_e x are taken first, so that only ONE cell-sized array (y,
 // initialised with x) stays live while the neighbours are visited.
 // minimum waves/SIMD requested from the compiler; 1 = no constraint.  Measured at C3 (k = 2, hybrid + Chebyshev):
@@ -185,7 +185,7 @@ void k_edge_lift(Geo g, DevTables T, const double* __restrict__ in,
                                                     double* __restrict__ out, const double* __restrict__ r,
                                                     const double* __restrict__ Dinv0, const double* __restrict__ Dinv1,
                                                     double* __restrict__ chd, double* __restrict__ chx, double c1,
-                                                    double c2) {
+                                                    double c2, double* __restrict__ cell_ss) {
   constexpr int NU = Dim<K>::NU, NE = Dim<K>::NE, N2 = 2 * NU;
   HDG_CELL_PROLOGUE
   double y[N2], down[3][NE];
@@ -217,6 +217,14 @@ void k_edge_lift(Geo g, DevTables T, const double* __restrict__ in,
     mv_acc<N2, NE>(Out, down[e], y, 1.0);
   }
   if (out) store_cell<N2>(out, g.Nc, c, y);
+  if (cell_ss) {
+    // squared norm of this cell's part of the result (convergence checks: a 1/N2-sized array instead of the
+    // whole vector goes through memory; summed deterministically by the multi-dot kernel)
+    double ss = 0.0;
+#pragma unroll
+    for (int n = 0; n < N2; n++) ss = fma(y[n], y[n], ss);
+    cell_ss[c] = ss;
+  }
   if (chd) {
     // The c1 == 0 case (first Chebyshev step: d is not read) is decided ONCE, outside the element loop: with
     // the test inside, every element became its own branch -> load -> wait -> store block, 2 N2 dependent
