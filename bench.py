@@ -192,8 +192,9 @@ def main():
         # launches that share ~55 % of the step (profiles/r01_i_kernel_stats_c3.csv: 28.6 % + 26.6 %):
         #   k_adv_apply (residual form): t = b - (I - gamma F(Q*)) x; reads x, Q*, b and writes t: 4 vectors;
         #   k_edge_lift<K,false,2> + Chebyshev step: z = t + sum_e G_e d_e(t) (BDM lift with the element
-        #     block-Jacobi folded into the lifting tables), d = c1 d + c2 z, x += d: reads t, d, x, writes d, x:
-        #     5 vectors (the additive preconditioner, --tent-precond 1, reads one more).
+        #     block-Jacobi folded into the lifting tables), x_{n+1} = x_n + c1 (x_n - x_{n-1}) + c2 z written over
+        #     x_{n-1}: reads t, x_n, x_{n-1}, writes x_{n+1}: 4 vectors (the additive preconditioner,
+        #     --tent-precond 1, reads one more).
         # 8 B per entry.  Whichever takes longer per launch is reported as the dominant
         # kernel, the other under other_kernels.  Durations from HIP events on the engine's stream.
         NQ = eng.n_cells * 2 * eng.n_u  # this rank's strip: kernel timings below are per-rank launches
@@ -206,7 +207,7 @@ def main():
         ms_tr = eng.time_kernel(1, 50)
         ms_bs = eng.time_kernel(3, 20)
         ms_triad = eng.time_kernel(8, 20)  # y = a x + b y on velocity vectors: the HBM rate this box actually delivers
-        lift_bytes = 8.0 * (5 if hybrid else 6) * NQ
+        lift_bytes = 8.0 * (4 if hybrid else 5) * NQ
         adv_bytes = 8.0 * 4 * NQ
         lift_name = ("k_edge_lift<K,false,2> (BDM lift + block-Jacobi of the remainder + Chebyshev step)" if hybrid
                      else "k_edge_lift<K,false,1> (BDM lift + block-Jacobi + Chebyshev step)")

@@ -589,8 +589,9 @@ struct Engine {
       bdm_hybrid(r, z, hybg0[didx], hybg1[didx]);
     }
   }
-  // z = M r fused with the Chebyshev step d = c1 d + c2 z, x += d (owned rows only: the ghost rows of x are
-  // refreshed by the next operator application); z is written to `zout` only when it is needed
+  // z = M r fused with the Chebyshev step x_{n+1} = x_n + c1 (x_n - x_{n-1}) + c2 z: d_ holds x_{n-1} on entry and
+  // x_{n+1} on exit, x_ = x_n is only read (owned rows only: the ghost rows are refreshed by the next operator
+  // application); z is written to `zout` only when it is needed
   // cell_norm (hybrid preconditioner only): instead of z the kernel writes |z_K|^2 per cell into cell_ss
   void tent_precond_cheb(int didx, const double* r, double* zout, double* d_, double* x_, double c1, double c2,
                          bool cell_norm = false) {
@@ -856,13 +857,19 @@ struct Engine {
       if (debug_on()) fprintf(stderr, "[cheb] stage %d: %d iterations predicted on [%.3f, %.3f] -> GMRES\n", didx, expected, lo, hi);
       return its + gmres(qstar, gamma, didx, b, x, rtol, cfg.tent_maxit, true, nullptr, 0, nullptr, nullptr, beta0);
     }
+    // Two iterate buffers, no direction vector: the step writes x_{n+1} over x_{n-1} (k_edge_lift epilogue /
+    // k_cheb_update), then the roles swap.  `cur` holds the newest iterate; x receives it when the solve ends.
+    double* cur = x;
+    double* oth = chd;
+    auto finish_in_x = [&]() { if (cur != x) copy(x, cur, NQ); };
     if (estimate) {
-      adv_apply(x, qstar, t, gamma, b);
-      tent_precond_cheb(didx, t, nullptr, chd, x, 0.0, 1.0 / theta);
+      adv_apply(cur, qstar, t, gamma, b);
+      tent_precond_cheb(didx, t, nullptr, oth, cur, 0.0, 1.0 / theta);
     } else {
       // z = M(b - A x) of the unchanged iterate is already in wQ1 (= z) from the norm evaluation above
-      k_cheb_update<<<nvb, 256, 0, stream>>>(NQ, chd, z, x, 0.0, 1.0 / theta);
+      k_cheb_update<<<nvb, 256, 0, stream>>>(NQ, oth, z, cur, 0.0, 1.0 / theta);
     }
+    std::swap(cur, oth);
     const int ch_head = its;  // iterations of the opening GMRES cycle (0 without an estimate)
     int k = 1;
     its++;
@@ -877,10 +884,11 @@ struct Engine {
       static const int fine_step = std::getenv("HDG_CHEB_FINE_STEP") ? std::atoi(std::getenv("HDG_CHEB_FINE_STEP")) : 2;
       const bool check = kfine > 0 ? (k < kfine ? (k % 8 == 0) : ((k - kfine) % fine_step == 0)) : (k % 4 == 0);
       const double rn = 1.0 / (2.0 * sigma - rho);
-      adv_apply(x, qstar, t, gamma, b);
+      adv_apply(cur, qstar, t, gamma, b);
       // hybrid preconditioner: the lift kernel emits |z_K|^2 per cell (N_c doubles) instead of z (N_Q doubles)
       const bool cell_norm = check && cfg.tent_precond == 2;
-      tent_precond_cheb(didx, t, (check && !cell_norm) ? z : nullptr, chd, x, rn * rho, 2.0 * rn / delta, cell_norm);
+      tent_precond_cheb(didx, t, (check && !cell_norm) ? z : nullptr, oth, cur, rn * rho, 2.0 * rn / delta, cell_norm);
+      std::swap(cur, oth);
       rho = rn;
       k++;
       its++;
@@ -893,6 +901,7 @@ struct Engine {
           // extra Chebyshev step only reduces the error further
           ch_slow[didx] = its > cheb_max_expected + cheb_max_expected / 2;  // the prediction was optimistic
           ch_last[didx] = its;
+          finish_in_x();
           return its;
         }
         // Guards.  Growth (an eigenvalue outside the ellipse of convergence): finish with GMRES and estimate
@@ -912,6 +921,7 @@ struct Engine {
           if (debug_on())
             fprintf(stderr, "[cheb]   falling back to GMRES at k=%d (%s; |Mr| %.2e, best %.2e)\n", k,
                     growing ? "growing" : "stalled", nz, last);
+          finish_in_x();
           return its + gmres(qstar, gamma, didx, b, x, rtol, cfg.tent_maxit, true, nullptr, 0, nullptr, nullptr, beta0);
         }
         last = std::min(last, nz);

@@ -169,8 +169,8 @@ __device__ __forceinline__ void mv_acc_ld(const double* __restrict__ A, int LD, 
 //              shape and stage, passed through Dinv0 / Dinv1 as 3 consecutive 2NU x NE blocks): the conforming
 //              part of the residual is kept, the non-conforming remainder goes through the element block-Jacobi,
 //              at the cost of the plain projection.
-//   Optional Chebyshev epilogue (chd != nullptr): with z the kernel's result,
-//   d = c1*d + c2*z ; x += d ; z itself is stored only if out != nullptr; cell_ss != nullptr: per-cell |z_K|^2.
+//   Optional Chebyshev epilogue (chd != nullptr): with z the kernel's result, x_{n+1} = x_n + c1 (x_n - x_{n-1}) + c2 z
+//   (chx = x_n, chd = x_{n-1} -> x_{n+1}); z itself is stored only if out != nullptr; cell_ss != nullptr: per-cell |z_K|^2.
 // Register diet: the cell's own normal moments -N_e x are taken first, so that only ONE cell-sized array (y,
 // initialised with x) stays live while the neighbours are visited.
 // minimum waves/SIMD requested from the compiler; 1 = no constraint.  Measured at C3 (k = 2, hybrid + Chebyshev):
@@ -226,30 +226,32 @@ void k_edge_lift(Geo g, DevTables T, const double* __restrict__ in,
     cell_ss[c] = ss;
   }
   if (chd) {
-    // The c1 == 0 case (first Chebyshev step: d is not read) is decided ONCE, outside the element loop: with
-    // the test inside, every element became its own branch -> load -> wait -> store block, 2 N2 dependent
-    // memory round trips per wave.  Here each half issues its N2 loads back to back, then N2 stores.
+    // Chebyshev step in three-term form on two iterate buffers (no direction vector):
+    //   x_{n+1} = x_n + c1 (x_n - x_{n-1}) + c2 z       chx = x_n (read only), chd = x_{n-1} on entry, x_{n+1} on exit
+    // i.e. 2 reads + 1 write per entry instead of the 2 + 2 of  d = c1 d + c2 z, x += d  (d_{n-1} = x_n - x_{n-1}).
+    // The c1 == 0 case (first step: x_{n-1} is not read) is decided ONCE, outside the element loop: with the test
+    // inside, every element became its own branch -> load -> wait -> store block.  Each half issues its loads back
+    // to back, then its stores.
     const bool rd = (c1 != 0.0);
-    const CellBuf Bd(chd), Bx(chx);
+    const CellBuf Bp(chd), Bx(chx);
     const unsigned lane_b = (unsigned)c * 8u;
 #pragma unroll
     for (int half = 0; half < 2; half++) {
       constexpr int H2 = N2 / 2;
-      double dd[H2], xx[H2];
+      double pp[H2], xx[H2];
 #pragma unroll
       for (int n = 0; n < H2; n++) xx[n] = Bx.ld(plane_bytes(half * H2 + n, g.Nc), lane_b);
       if (rd) {
 #pragma unroll
-        for (int n = 0; n < H2; n++) dd[n] = Bd.ld(plane_bytes(half * H2 + n, g.Nc), lane_b);
+        for (int n = 0; n < H2; n++) pp[n] = Bp.ld(plane_bytes(half * H2 + n, g.Nc), lane_b);
       } else {
 #pragma unroll
-        for (int n = 0; n < H2; n++) dd[n] = 0.0;
+        for (int n = 0; n < H2; n++) pp[n] = xx[n];
       }
 #pragma unroll
       for (int n = 0; n < H2; n++) {
-        const double dn = rd ? fma(c1, dd[n], c2 * y[half * H2 + n]) : c2 * y[half * H2 + n];
-        Bd.st(plane_bytes(half * H2 + n, g.Nc), lane_b, dn);
-        Bx.st(plane_bytes(half * H2 + n, g.Nc), lane_b, xx[n] + dn);
+        const double xn1 = fma(c1, xx[n] - pp[n], fma(c2, y[half * H2 + n], xx[n]));
+        Bp.st(plane_bytes(half * H2 + n, g.Nc), lane_b, xn1);
       }
     }
   }
@@ -1356,14 +1358,14 @@ __global__ void k_reduce_parts(int nblocks, int nv, const double* __restrict__ p
     res[k] = tot;
   }
 }
-// Chebyshev step on velocity vectors:  d = c1*d + c2*z ;  x += d
-__global__ void k_cheb_update(long N, double* __restrict__ d, const double* __restrict__ z, double* __restrict__ x,
+// Chebyshev step on velocity vectors, three-term form:  pn = x + c1 (x - pn) + c2 z   (pn: x_{n-1} -> x_{n+1})
+__global__ void k_cheb_update(long N, double* __restrict__ pn, const double* __restrict__ z, const double* __restrict__ x,
                               double c1, double c2) {
   const long stride = (long)gridDim.x * blockDim.x;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < N; idx += stride) {
-    const double dn = (c1 != 0.0) ? fma(c1, d[idx], c2 * z[idx]) : c2 * z[idx];
-    d[idx] = dn;
-    x[idx] += dn;
+    const double xv = x[idx];
+    const double pv = (c1 != 0.0) ? pn[idx] : xv;
+    pn[idx] = fma(c1, xv - pv, fma(c2, z[idx], xv));
   }
 }
 
