@@ -1072,18 +1072,17 @@ struct Engine {
     static const int nsm = std::getenv("HDG_TRACE_SMOOTH_ITS") ? std::atoi(std::getenv("HDG_TRACE_SMOOTH_ITS")) : 2;
     cheb_smooth(r, z, true, nsm);
     trace_apply(z, r, 1.0, -1.0, wL2);
-    halo_L(wL2);
-    k_trace_to_p1<<<corner_grid(), bs(), 0, stream>>>(g, NL, wL2, mg_b[0], dt.elen[0], dt.elen[2], dt.elen[1]);
+    // restriction to the vertex grid from OWNED edges only (no halo of wL2): the cut rows are completed when the
+    // gathered blocks are assembled
+    const int partial = mg_gather ? 1 : 0;
+    k_trace_to_p1<<<corner_grid_all(), bs(), 0, stream>>>(g_all, NL, wL2, mg_b[0], dt.elen[0], dt.elen[2], dt.elen[1], partial);
     if (mg_gather) {
-      // every rank contributes its (ny+1) vertex rows; owners' rows are copied into the global vector
+      // every rank contributes its (ny+1) vertex rows; one kernel assembles the global vector from the blocks
       const long blk = (long)(g.ny + 1) * (g.nx + 1);
       comm->allgather(mg_b[0] + (long)g.joff * (g.nx + 1), mg_gather, (size_t)blk, stream);
       n_gather++;
-      for (int r = 0; r < comm->size; r++) {
-        const long rows = g.ny + (r == comm->size - 1 ? 1 : 0);
-        HIPCHECK(hipMemcpyAsync(mg_b[0] + (long)r * g.ny * (g.nx + 1), mg_gather + (long)r * blk,
-                                sizeof(double) * rows * (g.nx + 1), hipMemcpyDeviceToDevice, stream));
-      }
+      const long nvtx = ((long)comm->size * g.ny + 1) * (g.nx + 1);
+      k_p1_assemble<<<vec_blocks(nvtx), 256, 0, stream>>>(comm->size, g.ny, g.nx + 1, mg_gather, mg_b[0], partial);
     }
     run_vcycle();
     k_p1_to_trace<<<corner_grid(), bs(), 0, stream>>>(g, NL, mg_x[0], z, 1.0, dt.elen[0], dt.elen[2], dt.elen[1]);

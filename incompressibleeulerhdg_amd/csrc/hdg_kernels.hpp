@@ -1733,10 +1733,13 @@ __global__ void k_p1_to_trace(Geo g, int NL, const double* __restrict__ xc, doub
     *p1 = accumulate * (*p1) + sl * r3 * 0.5 * (vb - va);
   }
 }
-// transpose: an OWNED vertex row gathers from its (up to six) incident edges (rows j and j-1; row -1
-// is the ghost row); writes the rank's rows of the global vertex vector
+// transpose: a vertex row gathers from its (up to six) incident edges (rows j and j-1); writes the rank's rows
+// joff .. joff+ny of the global vertex vector.  Strip partition (partial != 0, launched over rows 0..ny): every
+// rank sums its OWNED edges only, so no halo of the residual is needed -- the vertex row on a cut receives the
+// edges of the row below from the lower rank (its extra row ny: only those terms) and everything else from the
+// upper rank (its row 0 without them); k_p1_assemble adds the two parts.
 __global__ void k_trace_to_p1(Geo g, int NL, const double* __restrict__ l, double* __restrict__ rc, double lH, double lV,
-                              double lD) {
+                              double lD, int partial) {
   HDG_CORNER_PROLOGUE
   const int st = g.nx + 1;
   const double r3 = 0.57735026918962576451;
@@ -1747,14 +1750,35 @@ __global__ void k_trace_to_p1(Geo g, int NL, const double* __restrict__ l, doubl
   const double* D0 = l + ((long)2 * NL) * g.G;
   const double* D1 = l + ((long)2 * NL + 1) * g.G;
   const double sH = 0.5 * sqrt(lH), sV = 0.5 * sqrt(lV), sD = 0.5 * sqrt(lD);
+  const bool cut_lo = partial && g.joff > 0 && j == 0;                      // edges of row -1 belong to the lower rank
+  const bool extra = partial && (g.joff + g.ny < g.nyg) && j == g.ny;       // lower side of the cut above: row ny-1 only
+  const bool from_below = below && !cut_lo;
   double acc = 0.0;
-  if (i < g.nx) acc += sH * (H0[o] - r3 * H1[o]);                              // H(i,j): a-end
-  if (i > 0) acc += sH * (H0[o - 1] + r3 * H1[o - 1]);                         // H(i-1,j): b-end
-  if (in_y) acc += sV * (V0[o] - r3 * V1[o]);                                  // V(i,j): a-end
-  if (below) acc += sV * (V0[o - g.P] + r3 * V1[o - g.P]);                     // V(i,j-1): b-end
-  if (i > 0 && in_y) acc += sD * (D0[o - 1] - r3 * D1[o - 1]);                 // D(i-1,j): a-end (x_i,y_j)
-  if (i < g.nx && below) acc += sD * (D0[o - g.P] + r3 * D1[o - g.P]);         // D(i,j-1): b-end (x_i,y_j)
+  if (!extra) {
+    if (i < g.nx) acc += sH * (H0[o] - r3 * H1[o]);                            // H(i,j): a-end
+    if (i > 0) acc += sH * (H0[o - 1] + r3 * H1[o - 1]);                       // H(i-1,j): b-end
+    if (in_y) acc += sV * (V0[o] - r3 * V1[o]);                                // V(i,j): a-end
+  }
+  if (from_below) acc += sV * (V0[o - g.P] + r3 * V1[o - g.P]);                // V(i,j-1): b-end
+  if (!extra && i > 0 && in_y) acc += sD * (D0[o - 1] - r3 * D1[o - 1]);       // D(i-1,j): a-end (x_i,y_j)
+  if (i < g.nx && from_below) acc += sD * (D0[o - g.P] + r3 * D1[o - g.P]);    // D(i,j-1): b-end (x_i,y_j)
   rc[(long)(g.joff + j) * st + i] = acc;
+}
+// global vertex vector from the all-gathered blocks of (ny+1) rows per rank, in ONE launch: rank r owns the rows
+// r*ny .. (r+1)*ny-1 (the last rank also the top row); on a cut the lower rank's extra row is added (partial sums)
+__global__ void k_p1_assemble(int P, int ny, int st, const double* __restrict__ gathered, double* __restrict__ out,
+                              int partial) {
+  const long n = ((long)P * ny + 1) * st, blk = (long)(ny + 1) * st;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += stride) {
+    const int R = (int)(idx / st), i = (int)(idx - (long)R * st);
+    int r = R / ny;
+    if (r > P - 1) r = P - 1;
+    const int lr = R - r * ny;
+    double v = gathered[r * blk + (long)lr * st + i];
+    if (partial && lr == 0 && r > 0) v += gathered[(r - 1) * blk + (long)ny * st + i];
+    out[idx] = v;
+  }
 }
 
 // ------------------------------------------------------------------------------------------
