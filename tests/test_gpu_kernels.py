@@ -152,3 +152,19 @@ def test_two_lane_advection_kernel_all_degrees(hip_lib):
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     assert r.returncode == 0, r.stdout.decode()[-2000:]
     assert r.stdout.decode().count("e-") == 8
+
+
+def test_time_kernel_ids_and_errors(hip_lib):
+    """hdg_time_kernel (bench.py's roofline probe): every documented kernel id runs and returns a positive
+    duration, for both preconditioner variants; an unknown id is an argument error, not a crash."""
+    from incompressibleeulerhdg_amd import _lib
+
+    for tp in (1, 2):
+        d, e = _setup(2, 16, tent_precond=tp)
+        rng = np.random.default_rng(5)
+        e.set_state(rng.standard_normal(e.shape_Q), rng.standard_normal(e.shape_p))
+        for kid in range(9):
+            ms = e.time_kernel(kid, 3)
+            assert 0.0 < ms < 50.0, (tp, kid, ms)
+        with pytest.raises(_lib.HDGError):
+            e.time_kernel(99, 1)
