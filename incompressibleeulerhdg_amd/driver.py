@@ -3,7 +3,8 @@
     python -m incompressibleeulerhdg_amd.driver --nx 64 --degree 2 --use_projection_method
 
 Out of scope here: ``--animation``, ``--tracer_advection``, the
-``kelvinhelmholtz`` / ``shear`` problems, the ``conforming`` / ``dg`` discretisations and VTK output.
+``kelvinhelmholtz`` / ``shear`` problems and the ``conforming`` / ``dg`` discretisations.  The final fields are
+written to ``solution.pvd`` (``--output``) like the reference does (driver.py:356-385).
 """
 import argparse
 import sys
@@ -14,6 +15,7 @@ import numpy as np
 from .auxilliary.logging import log_summary
 from .mesh import Function, UnitSquareMesh
 from .model_problems import TaylorGreen
+from .output import VTKFile
 from .timesteppers import (
     IncompressibleEulerHDGIMEXARS2_232,
     IncompressibleEulerHDGIMEXARS3_443,
@@ -54,6 +56,8 @@ def build_parser():
     parser.add_argument("--tracer_advection", action="store_true", default=False, help="(out of scope)")
     # additions of the build
     parser.add_argument("--fused", action="store_true", default=False, help="run each timestep as one device-resident call")
+    parser.add_argument("--output", type=str, default="solution.pvd",
+                        help="VTK collection written at the end like the reference's solution.pvd ('' = no output)")
     parser.add_argument("--device", type=int, default=0, help="HIP device ordinal")
     return parser
 
@@ -141,6 +145,13 @@ def main(argv=None):
         print(f"velocity error = {Q_error_nrm}")
         print(f"pressure error = {p_error_nrm}")
         print()
+        if args.output:
+            # driver.py:356-385: L2 projection of the (broken) divergence onto the pressure space, then
+            # velocity, pressure, divergence, exact fields and errors into solution.pvd
+            divQ = Function(timestepper._V_p, eng.apply_weak_divergence(Q.dat.data, broken=True), "divergence")
+            Q_exact.rename("velocity_exact")
+            p_exact.rename("pressure_exact")
+            VTKFile(args.output).write(Q, p, divQ, Q_exact, Q_error, p_exact, p_error)
     return 0
 
 

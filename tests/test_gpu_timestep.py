@@ -150,7 +150,7 @@ def test_driver_prints_reference_quantities(hip_lib, capsys):
     """driver.py:284-306,379-380: same parameter echo and the two error norms."""
     from incompressibleeulerhdg_amd import driver
 
-    rc = driver.main(["--nx", "8", "--degree", "1", "--dt", "0.05", "--tfinal", "0.2", "--use_projection_method"])
+    rc = driver.main(["--nx", "8", "--degree", "1", "--dt", "0.05", "--tfinal", "0.2", "--use_projection_method", "--output", ""])
     out = capsys.readouterr().out
     assert rc == 0
     for needle in ("mesh size = 8 x 8", "timestepping method = HDG IMEX SSP2(3,3,2)", "number of Richardson iterations = 2",
