@@ -314,8 +314,64 @@ struct Engine {
   void halo_P(const double* v) { halo_rows(const_cast<double*>(v), (long)(g.ny + 2) * g.nx, g.nx, NP * 2); }
   void halo_L(const double* v) { halo_rows(const_cast<double*>(v), g.G, g.P, 3 * NL); }
 
+  // ---- MFMA lift (k >= 3): tables in A-operand lane order for k_edge_lift_mfma.  Tile (mt, ks) of a matrix M:
+  // 64 doubles, entry l = M[16 mt + l % 16][4 ks + l / 16] (zero outside M).  Order: W (2 M-tiles), N'_0..2, G.
+  // Out[e]: 2nu x ne row-major lifting tables of shape s (Lift_e for the projection, (I - Dinv) Lift_e for the
+  // hybrid preconditioner).
+  std::vector<double> pack_lift_mfma(int s_, const dvec* Out) const {
+    const int n2 = 2 * tab->nu, ne = tab->ne, KS = (n2 + 3) / 4, MT = (n2 + 15) / 16, KD = 5;
+    auto tile = [&](std::vector<double>& dstv, int rows, int cols, const std::vector<double>& M, int mt, int ks) {
+      for (int l = 0; l < 64; l++) {
+        const int r = 16 * mt + l % 16, c = 4 * ks + l / 16;
+        dstv.push_back((r < rows && c < cols) ? M[(size_t)r * cols + c] : 0.0);
+      }
+    };
+    std::vector<double> packed;
+    // W: rows (e, a) packed as tile 0 = edges 0, 1, tile 1 = edge 2;  W = -N[s][e]
+    std::vector<double> W((size_t)32 * n2, 0.0);
+    for (int e = 0; e < 3; e++)
+      for (int a = 0; a < ne; a++)
+        for (int n = 0; n < n2; n++) W[(size_t)((e < 2 ? e * ne + a : 16 + a)) * n2 + n] = -tab->N[s_][e][a * n2 + n];
+    for (int mt = 0; mt < 2; mt++) for (int ks = 0; ks < KS; ks++) tile(packed, 32, n2, W, mt, ks);
+    // N'_e = N[1 - s][e], rows at their position inside the tile
+    for (int e = 0; e < 3; e++) {
+      std::vector<double> Np((size_t)16 * n2, 0.0);
+      for (int a = 0; a < ne; a++)
+        for (int n = 0; n < n2; n++) Np[(size_t)((e == 1 ? ne : 0) + a) * n2 + n] = tab->N[1 - s_][e][a * n2 + n];
+      for (int ks = 0; ks < KS; ks++) tile(packed, 16, n2, Np, 0, ks);
+    }
+    // G: columns = packed moments, K index q: q < 12 -> tile 0 row q, q >= 12 -> tile 1 row q - 12
+    std::vector<double> Gm((size_t)(16 * MT) * 20, 0.0);
+    for (int e = 0; e < 3; e++)
+      for (int a = 0; a < ne; a++) {
+        const int q = e < 2 ? e * ne + a : 12 + a;
+        for (int n = 0; n < n2; n++) Gm[(size_t)n * 20 + q] = Out[e][(size_t)n * ne + a];
+      }
+    for (int mt = 0; mt < MT; mt++) for (int kd = 0; kd < KD; kd++) tile(packed, 16 * MT, 20, Gm, mt, kd);
+    return packed;
+  }
+  const double* liftm_plain[2] = {nullptr, nullptr};  // packed tables of the plain BDM projection
+  std::vector<double*> liftm_hyb0, liftm_hyb1;         // per stage: hybrid preconditioner
+  bool use_mfma_lift() const {
+    static const bool off = std::getenv("HDG_NO_MFMA_LIFT") != nullptr;
+    return !off && cfg.degree >= 3;
+  }
+  void lift_mfma(const double* t0, const double* t1, const double* in, double* out) {
+    const dim3 grid(8 * g.rows_xcd * 2);
+    switch (cfg.degree) {
+      case 3: k_edge_lift_mfma<3><<<grid, 64 * HDG_LIFT_MFMA_WAVES, 0, stream>>>(g, t0, t1, in, out); break;
+      case 4: k_edge_lift_mfma<4><<<grid, 64 * HDG_LIFT_MFMA_WAVES, 0, stream>>>(g, t0, t1, in, out); break;
+      default: throw std::string("MFMA lift: degree out of range");
+    }
+  }
   void bdm(const double* in, double* out) {
     halo_Q(in);
+    if (use_mfma_lift()) {
+      if (!liftm_plain[0])
+        for (int sh = 0; sh < 2; sh++) liftm_plain[sh] = upload(pack_lift_mfma(sh, tab->Lift[sh]));
+      lift_mfma(liftm_plain[0], liftm_plain[1], in, out);
+      return;
+    }
     HDG_DISPATCH(k_edge_lift<KK, false, 0><<<cell_grid(), bs(), 0, stream>>>(g, dt, in, out, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, 0.0, nullptr));
   }
   // out = Pi(in) + Dinv r   (second half of the two-level preconditioner, block-Jacobi fused in)
@@ -329,6 +385,11 @@ struct Engine {
   void bdm_hybrid(const double* in, double* out, const double* D0, const double* D1, double* chd_ = nullptr,
                   double* chx_ = nullptr, double c1 = 0.0, double c2 = 0.0, double* ss = nullptr) {
     halo_Q(in);
+    if (use_mfma_lift() && out && !chd_ && !ss) {
+      // GMRES path at k >= 3: no Chebyshev epilogue -> matrix-core kernel with the packed G tables of this stage
+      for (size_t q = 0; q < hybg0.size(); q++)
+        if (hybg0[q] == D0) { lift_mfma(liftm_hyb0[q], liftm_hyb1[q], in, out); return; }
+    }
     HDG_DISPATCH(k_edge_lift<KK, false, 2><<<cell_grid(), bs(), 0, stream>>>(g, dt, in, out, nullptr, D0, D1, chd_, chx_, c1, c2, ss));
   }
   void bdm_T(const double* in, double* out) {
@@ -571,6 +632,19 @@ struct Engine {
             for (int m = 0; m < n2; m++) acc -= Di[(size_t)r * n2 + m] * tab->Lift[sh][e][m * ne + q];
             G[sh][((size_t)e * n2 + r) * ne + q] = acc;
           }
+    }
+    if (use_mfma_lift()) {
+      // the same tables in A-operand lane order for k_edge_lift_mfma (G[sh]: 3 blocks of 2nu x ne)
+      if (liftm_hyb0.size() < hybg0.size()) { liftm_hyb0.resize(hybg0.size(), nullptr); liftm_hyb1.resize(hybg0.size(), nullptr); }
+      for (int sh = 0; sh < 2; sh++) {
+        dvec Ge[3];
+        for (int e = 0; e < 3; e++) Ge[e].assign(G[sh].begin() + (size_t)e * n2 * ne, G[sh].begin() + (size_t)(e + 1) * n2 * ne);
+        std::vector<double> pk = pack_lift_mfma(sh, Ge);
+        double*& dstp = sh == 0 ? liftm_hyb0[idx] : liftm_hyb1[idx];
+        if (!dstp) dstp = dalloc((long)pk.size());
+        HIPCHECK(hipMemcpyAsync(dstp, pk.data(), sizeof(double) * pk.size(), hipMemcpyHostToDevice, stream));
+        HIPCHECK(hipStreamSynchronize(stream));  // pk goes out of scope
+      }
     }
     if (!hybg0[idx]) { hybg0[idx] = dalloc((long)G[0].size()); hybg1[idx] = dalloc((long)G[1].size()); }
     HIPCHECK(hipMemcpyAsync(hybg0[idx], G[0].data(), sizeof(double) * G[0].size(), hipMemcpyHostToDevice, stream));

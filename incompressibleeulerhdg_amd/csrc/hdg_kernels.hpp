@@ -258,6 +258,123 @@ void k_edge_lift(Geo g, DevTables T, const double* __restrict__ in,
 }
 
 // ------------------------------------------------------------------------------------------
+// K1 on the matrix cores (k >= 3).  At high order the per-thread formulation above is limited by operand
+// delivery (tables through scalar loads, 228-256 VGPRs, 0.8-1.6 TB/s); the same three contractions as MFMA:
+//   (1) own normal moments      d   = -W x              W: packed (edge, moment) rows x 2NU
+//   (2) neighbour moments       d_e += N'_e x_nbr(e)     then d *= 1/2 where the neighbour exists
+//   (3) lifting                 y   = x + G d            G: 2NU x packed moments (Lift_e, or (I - Dinv) Lift_e)
+// One wave owns 16 consecutive cells of one shape and row (the N dimension of v_mfma_f64_16x16x4); the
+// coefficient planes in[n*Nc + c] are the B operands (lane l: plane 4ks + l/16, cell c0 + l%16 -- 128-byte
+// segments); the tables are packed on the host in A-operand lane order (Engine::pack_lift_mfma), staged in LDS
+// once per workgroup and read back one tile per MFMA (conflict-free ds_read_b64); d changes from accumulator
+// to operand layout through a 4 KB LDS slab per wave.  Packed moment rows: tile 0 = edges 0 and 1 (rows e*NE+a),
+// tile 1 = edge 2 (rows a).  A workgroup (8 waves sharing one LDS copy of the tables) handles one (row, shape);
+// wave w the tiles w, w+8, ...
+// ------------------------------------------------------------------------------------------
+typedef double hdg_v4d __attribute__((ext_vector_type(4)));
+template <int K>
+struct LiftMfma {
+  static constexpr int NU = Dim<K>::NU, NE = Dim<K>::NE, N2 = 2 * NU;
+  static constexpr int KS = (N2 + 3) / 4;    // K-steps over the coefficient planes
+  static constexpr int MT = (N2 + 15) / 16;  // M-tiles of the result
+  static constexpr int KD = 5;               // K-steps over the packed moments: 3 (tile 0, rows 0..11) + 2 (tile 1, rows 0..7)
+  static constexpr int NTILES = 2 * KS + 3 * KS + MT * KD;  // W (2 M-tiles), N'_e (3), G
+  static_assert(2 * NE <= 12 && NE <= 8, "packed moment rows do not fit the K-steps");
+};
+#ifndef HDG_LIFT_MFMA_WAVES
+#define HDG_LIFT_MFMA_WAVES 8
+#endif
+template <int K>
+__global__ __launch_bounds__(64 * HDG_LIFT_MFMA_WAVES) void k_edge_lift_mfma(Geo g, const double* __restrict__ tabs0, const double* __restrict__ tabs1,
+                                                         const double* __restrict__ in, double* __restrict__ out) {
+  typedef LiftMfma<K> L;
+  constexpr int NE = L::NE, N2 = L::N2, KS = L::KS, MT = L::MT, KD = L::KD;
+  __shared__ double tab[L::NTILES * 64];
+  // per-wave slab for the moments: rows 0..11 = tile 0 (edges 0, 1), rows 12..19 = tile 1 rows 0..7 (edge 2)
+  __shared__ double dst[HDG_LIFT_MFMA_WAVES][20][16];
+  // (xcd band, row, shape) of this workgroup
+  const int xcd_ = blockIdx.x & 7, q_ = blockIdx.x >> 3;
+  const int jj_ = q_ >> 1, s = q_ & 1;
+  const int j = xcd_ * g.rows_xcd + jj_;
+  if (jj_ >= g.rows_xcd || j >= g.ny) return;  // whole workgroup
+  const double* __restrict__ tsrc = s == 0 ? tabs0 : tabs1;
+  for (int p = threadIdx.x; p < L::NTILES * 64; p += 64 * HDG_LIFT_MFMA_WAVES) tab[p] = tsrc[p];
+  __syncthreads();
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63, li = l & 15, lk = l >> 4;
+  const double* __restrict__ tW = tab;                     // [2][KS][64]
+  const double* __restrict__ tN = tab + 2 * KS * 64;       // [3][KS][64]
+  const double* __restrict__ tG = tab + 5 * KS * 64;       // [MT][KD][64]
+  const int gj = g.joff + j;
+  const bool has0 = s == 0 ? gj > 0 : gj < g.nyg - 1;
+  const int jn0 = s == 0 ? j - 1 : j + 1;
+  const long rowN0 = ((long)(1 - s) * (g.ny + 2) + (jn0 + 1)) * g.nx, rowN = ((long)(1 - s) * (g.ny + 2) + (j + 1)) * g.nx;
+  const long rowC = ((long)s * (g.ny + 2) + (j + 1)) * g.nx;
+  const int ntx = (g.nx + 15) >> 4;
+  for (int tx = w; tx < ntx; tx += HDG_LIFT_MFMA_WAVES) {
+    const int i = tx * 16 + li;
+    const bool col = i < g.nx;
+    const int ic = col ? i : g.nx - 1;  // clamped: loads stay in bounds, results of invalid columns are not stored
+    const bool has2 = s == 0 ? i > 0 : i < g.nx - 1;
+    const int i2 = s == 0 ? ic - 1 : ic + 1;
+    const long c = rowC + ic, cn0 = rowN0 + ic, cn1 = rowN + ic, cn2 = rowN + (has2 ? i2 : ic);
+    // (1) own moments
+    hdg_v4d D0 = {0, 0, 0, 0}, D1 = {0, 0, 0, 0};
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) {
+      const int n = 4 * ks + lk;
+      const double b = (n < N2) ? in[(long)n * g.Nc + c] : 0.0;
+      D0 = __builtin_amdgcn_mfma_f64_16x16x4f64(tW[(0 * KS + ks) * 64 + l], b, D0, 0, 0, 0);
+      D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(tW[(1 * KS + ks) * 64 + l], b, D1, 0, 0, 0);
+    }
+    // (2) neighbours: edges 0, 1 -> tile 0, edge 2 -> tile 1 (a missing neighbour contributes zeros)
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) {
+      const int n = 4 * ks + lk;
+      const bool nv = n < N2;
+      const double b0 = (nv && has0) ? in[(long)n * g.Nc + cn0] : 0.0;
+      const double b1 = nv ? in[(long)n * g.Nc + cn1] : 0.0;
+      const double b2 = (nv && has2) ? in[(long)n * g.Nc + cn2] : 0.0;
+      D0 = __builtin_amdgcn_mfma_f64_16x16x4f64(tN[(0 * KS + ks) * 64 + l], b0, D0, 0, 0, 0);
+      D0 = __builtin_amdgcn_mfma_f64_16x16x4f64(tN[(1 * KS + ks) * 64 + l], b1, D0, 0, 0, 0);
+      D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(tN[(2 * KS + ks) * 64 + l], b2, D1, 0, 0, 0);
+    }
+    // weights: 1/2 where the neighbour exists.  Accumulator layout (measured): lane (lk, li) register r holds
+    // row lk + 4 r of column li
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int row = lk + 4 * r;
+      D0[r] *= (row < NE) ? (has0 ? 0.5 : 1.0) : 0.5;  // rows NE .. 2NE-1: edge 1 always has its neighbour
+      D1[r] *= has2 ? 0.5 : 1.0;
+      if (row < 12) dst[w][row][li] = D0[r];
+      if (row < 8) dst[w][12 + row][li] = D1[r];
+    }
+    // the slab is private to the wave: LDS operations of one wave execute in order, a wave-level barrier keeps the
+    // compiler from moving the reads above the writes
+    __builtin_amdgcn_wave_barrier();
+    // (3) lifting: y = x + G d, d as B operand: K-steps 0..2 = tile 0 rows 0..11, 3..4 = tile 1 rows 0..7
+    double bd[KD];
+#pragma unroll
+    for (int kd = 0; kd < KD; kd++) bd[kd] = dst[w][4 * kd + lk][li];  // K index q: 0..11 tile 0, 12..19 tile 1
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) {
+      hdg_v4d Y;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int n = 16 * mt + lk + 4 * r;
+        Y[r] = (n < N2) ? in[(long)n * g.Nc + c] : 0.0;
+      }
+#pragma unroll
+      for (int kd = 0; kd < KD; kd++) Y = __builtin_amdgcn_mfma_f64_16x16x4f64(tG[(mt * KD + kd) * 64 + l], bd[kd], Y, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int n = 16 * mt + lk + 4 * r;
+        if (n < N2 && col) out[(long)n * g.Nc + c] = Y[r];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // K3  advection apply:  y = x - gamma * F(Q*) x     with F = f_impl (hdg_imex.py:313-331):
 //   F_K(x)[w] = sum_{e int} int_e [ (1/2)(Q*.n_K) - up |Q*.n_K| ] (x_K - x_K').w
 //             - int_K w.((Q*.grad) x)  -  sum_e alpha/h_F int_e ((x_K - x_K').n)(w.n)

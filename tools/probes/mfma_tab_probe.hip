@@ -37,7 +37,8 @@ __global__ __launch_bounds__(128) void k_scalar(const double* __restrict__ T, co
 }
 
 // one wave: 16 cells per trip.  A tile (mt, ks): lane l holds T[16 mt + l % 16][4 ks + l / 16];
-// B tile (ks): lane l holds x[4 ks + l / 16][c0 + l % 16]; D tile (mt): lane l holds y[16 mt + 4 (l / 16) + r][c0 + l % 16]
+// B tile (ks): lane l holds x[4 ks + l / 16][c0 + l % 16]; D tile (mt): register r of lane l holds
+// y[16 mt + (l / 16) + 4 r][c0 + l % 16]  (only the sum over rows is used here)
 __global__ __launch_bounds__(64) void k_mfma(const double* __restrict__ T, const double* __restrict__ x, double* __restrict__ s,
                                              long Nc, int trips) {
   const int l = threadIdx.x, li = l & 15, lk = l >> 4;
