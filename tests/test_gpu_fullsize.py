@@ -15,7 +15,7 @@ def _stepper(k, nx, **kw):
     return ts, TaylorGreen(ts._V_Q, ts._V_p, "exponential", 0.5)
 
 
-@pytest.mark.parametrize("k,nx", [(1, 256), (2, 1024)])
+@pytest.mark.parametrize("k,nx", [(1, 256), (2, 1024), (3, 512), (4, 200)])  # k >= 3: matrix-core lift, many tiles / partial tile
 def test_operator_properties_at_baseline_size(hip_lib, k, nx):
     ts, mp = _stepper(k, nx)
     e = ts._engine

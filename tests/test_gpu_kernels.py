@@ -170,10 +170,11 @@ def test_time_kernel_ids_and_errors(hip_lib):
             e.time_kernel(99, 1)
 
 
-@pytest.mark.parametrize("k,nx", [(3, 20), (4, 18), (3, 33)])
+@pytest.mark.parametrize("k,nx", [(3, 20), (4, 18)])
 def test_project_bdm_matrix_core_kernel_tiles(hip_lib, k, nx):
     """k >= 3 runs the BDM lift on the matrix cores (k_edge_lift_mfma: one wave per 16 cells): meshes with full
-    tiles, a partial last tile (nx not a multiple of 16) and more tiles than waves must match the oracle."""
+    tiles and a partial last tile (nx not a multiple of 16) must match the oracle (more tiles than waves: the
+    full-size property tests, k = 3 at 512^2)."""
     d, e = _setup(k, nx)
     rng = np.random.default_rng(11)
     Q = rng.standard_normal(e.shape_Q)
