@@ -350,6 +350,28 @@ struct Engine {
     for (int mt = 0; mt < MT; mt++) for (int kd = 0; kd < KD; kd++) tile(packed, 16 * MT, 20, Gm, mt, kd);
     return packed;
   }
+  // tables of k_adv_cell_mfma in A-operand lane order: Phi, Gx, Gy (rows = quadrature points, columns = basis
+  // functions), then A2[m][q] = -w_q Phi[q][m] (rows = basis functions, columns = quadrature points)
+  std::vector<double> pack_adv_mfma(int s_) const {
+    const int nu = tab->nu, nq = tab->nqc, MTQ = (nq + 15) / 16, KSU = (nu + 3) / 4, MTU = (nu + 15) / 16;
+    std::vector<double> packed;
+    auto tile = [&](int rows, int cols, const std::vector<double>& M, int mt, int ks) {
+      for (int l = 0; l < 64; l++) {
+        const int r = 16 * mt + l % 16, c = 4 * ks + l / 16;
+        packed.push_back((r < rows && c < cols) ? M[(size_t)r * cols + c] : 0.0);
+      }
+    };
+    const dvec* T3[3] = {&tab->cPhi[s_], &tab->cGx[s_], &tab->cGy[s_]};
+    for (int t = 0; t < 3; t++) {
+      std::vector<double> M(T3[t]->begin(), T3[t]->end());  // nq x nu
+      for (int mt = 0; mt < MTQ; mt++) for (int ks = 0; ks < KSU; ks++) tile(nq, nu, M, mt, ks);
+    }
+    std::vector<double> A2((size_t)nu * nq);
+    for (int m = 0; m < nu; m++) for (int q = 0; q < nq; q++) A2[(size_t)m * nq + q] = -tab->cw[q] * tab->cPhi[s_][(size_t)q * nu + m];
+    for (int mu = 0; mu < MTU; mu++) for (int ks = 0; ks < 4 * MTQ; ks++) tile(nu, nq, A2, mu, ks);
+    return packed;
+  }
+  const double* advm[2] = {nullptr, nullptr};
   const double* liftm_plain[2] = {nullptr, nullptr};  // packed tables of the plain BDM projection
   std::vector<double*> liftm_hyb0, liftm_hyb1;         // per stage: hybrid preconditioner
   bool use_mfma_lift() const {
@@ -399,6 +421,25 @@ struct Engine {
   void adv_apply(const double* x, const double* qstar, double* out, double gamma, const double* bsub = nullptr) {
     halo_Q(x);
     const double up = cfg.flux_upwind ? 1.0 : 0.0;
+    // k >= 3: cell term on the matrix cores, facet terms in a two-lane kernel (k_adv_cell_mfma + k_adv_edges2)
+    static const bool no_mfma_adv = std::getenv("HDG_NO_MFMA_ADV") != nullptr;
+    if (!no_mfma_adv && cfg.degree >= 3) {
+      if (!advm[0]) {
+        if (dt.nqc != (cfg.degree == 3 ? 36 : 64)) throw std::string("cell quadrature size does not match the matrix-core advection kernel");
+        for (int sh = 0; sh < 2; sh++) advm[sh] = upload(pack_adv_mfma(sh));
+      }
+      const dim3 gridc(8 * g.rows_xcd * 2);
+      const int cpb = bs() / 2, nbx2 = (g.nx + cpb - 1) / cpb;
+      const dim3 gride(8 * g.rows_xcd * 2 * nbx2);
+      if (cfg.degree == 3) {
+        k_adv_cell_mfma<3><<<gridc, 256, 0, stream>>>(g, advm[0], advm[1], x, qstar, out);
+        k_adv_edges2<3><<<gride, bs(), 0, stream>>>(g, dt, x, qstar, out, gamma, up, bsub);
+      } else {
+        k_adv_cell_mfma<4><<<gridc, 256, 0, stream>>>(g, advm[0], advm[1], x, qstar, out);
+        k_adv_edges2<4><<<gride, bs(), 0, stream>>>(g, dt, x, qstar, out, gamma, up, bsub);
+      }
+      return;
+    }
     // k = 3: two lanes per cell, one velocity component each (k_adv_apply2).  Measured at nx = 512, one-lane vs
     // two-lane kernel: k=1 181 / 205 us (nx 1024), k=2 353 / 370 us (nx 1024), k=3 407 / 334 us, k=4 719 / 1488 us
     // (254 VGPRs, still 1 wave/SIMD, twice the waves).  HDG_ADV_SPLIT=lo:hi overrides the degree range.

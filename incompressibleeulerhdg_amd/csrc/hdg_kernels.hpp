@@ -581,6 +581,178 @@ __global__ __launch_bounds__(128) void k_adv_apply2(Geo g, DevTables T, const do
 }
 
 // ------------------------------------------------------------------------------------------
+// K3 on the matrix cores (k >= 3), in two launches:
+//   k_adv_cell_mfma  cell term  F_cell[m] = -sum_q w_q Phi[q,m] (Q*(q) . grad) x (q)   -> out (raw, not yet combined)
+//   k_adv_edges2     facet terms added to it, then  out = x - gamma F  (or  b - (x - gamma F))
+// Cell kernel, mapping of k_edge_lift_mfma (one wave per 16 cells, tables packed on the host in A-operand lane
+// order and staged in LDS).  Per block of 16 quadrature points: six contractions over the NU basis functions
+// (Q*_x, Q*_y = Phi q*, d_x x_a, d_y x_a = Gx / Gy x_a) as MFMA chains with the coefficient planes as B operands,
+// the pointwise product on the accumulators, a 4 KB LDS slab per wave to turn the result into a B operand, and
+// the test contraction with A2[m][q] = -w_q Phi[q][m] accumulated over the blocks.
+// ------------------------------------------------------------------------------------------
+template <int K>
+struct AdvMfma {
+  static constexpr int NU = Dim<K>::NU;
+  static constexpr int NQ = (K == 3) ? 36 : 64;   // cell quadrature points (collapsed Gauss-Jacobi, Tables::nqc)
+  static constexpr int MTQ = (NQ + 15) / 16, KSU = (NU + 3) / 4, MTU = (NU + 15) / 16;
+  static constexpr int NT1 = MTQ * KSU;            // tiles per stage-1 table
+  static constexpr int NTILES = 3 * NT1 + MTU * 4 * MTQ;
+};
+template <int K>
+__global__ __launch_bounds__(256) void k_adv_cell_mfma(Geo g, const double* __restrict__ tabs0, const double* __restrict__ tabs1,
+                                                        const double* __restrict__ xin, const double* __restrict__ qstar,
+                                                        double* __restrict__ out) {
+  typedef AdvMfma<K> A;
+  constexpr int NU = A::NU, MTQ = A::MTQ, KSU = A::KSU, MTU = A::MTU, NT1 = A::NT1;
+  __shared__ double tab[A::NTILES * 64];
+  __shared__ double slab[4][2][16][16];
+  const int xcd_ = blockIdx.x & 7, q_ = blockIdx.x >> 3;
+  const int jj_ = q_ >> 1, s = q_ & 1;
+  const int j = xcd_ * g.rows_xcd + jj_;
+  if (jj_ >= g.rows_xcd || j >= g.ny) return;  // whole workgroup
+  const double* __restrict__ tsrc = s == 0 ? tabs0 : tabs1;
+  for (int p = threadIdx.x; p < A::NTILES * 64; p += 256) tab[p] = tsrc[p];
+  __syncthreads();
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63, li = l & 15, lk = l >> 4;
+  const double* __restrict__ tPhi = tab;
+  const double* __restrict__ tGx = tab + NT1 * 64;
+  const double* __restrict__ tGy = tab + 2 * NT1 * 64;
+  const double* __restrict__ tA2 = tab + 3 * NT1 * 64;  // [MTU][4 MTQ][64]
+  const long rowC = ((long)s * (g.ny + 2) + (j + 1)) * g.nx;
+  const int ntx = (g.nx + 15) >> 4;
+  for (int tx = w; tx < ntx; tx += 4) {
+    const int i = tx * 16 + li;
+    const bool col = i < g.nx;
+    const long c = rowC + (col ? i : g.nx - 1);
+    double bq0[KSU], bq1[KSU], bx0[KSU], bx1[KSU];
+#pragma unroll
+    for (int ks = 0; ks < KSU; ks++) {
+      const int m = 4 * ks + lk;
+      const bool mv = m < NU;
+      bq0[ks] = mv ? qstar[(long)m * g.Nc + c] : 0.0;
+      bq1[ks] = mv ? qstar[(long)(NU + m) * g.Nc + c] : 0.0;
+      bx0[ks] = mv ? xin[(long)m * g.Nc + c] : 0.0;
+      bx1[ks] = mv ? xin[(long)(NU + m) * g.Nc + c] : 0.0;
+    }
+    hdg_v4d F[2][MTU];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+      for (int mu = 0; mu < MTU; mu++) F[a][mu] = hdg_v4d{0, 0, 0, 0};
+#pragma unroll
+    for (int mt = 0; mt < MTQ; mt++) {
+      hdg_v4d QX = {0, 0, 0, 0}, QY = QX, DXX = QX, DXY = QX, DYX = QX, DYY = QX;
+#pragma unroll
+      for (int ks = 0; ks < KSU; ks++) {
+        const double ap = tPhi[(mt * KSU + ks) * 64 + l], ax_ = tGx[(mt * KSU + ks) * 64 + l], ay_ = tGy[(mt * KSU + ks) * 64 + l];
+        QX = __builtin_amdgcn_mfma_f64_16x16x4f64(ap, bq0[ks], QX, 0, 0, 0);
+        QY = __builtin_amdgcn_mfma_f64_16x16x4f64(ap, bq1[ks], QY, 0, 0, 0);
+        DXX = __builtin_amdgcn_mfma_f64_16x16x4f64(ax_, bx0[ks], DXX, 0, 0, 0);
+        DXY = __builtin_amdgcn_mfma_f64_16x16x4f64(ay_, bx0[ks], DXY, 0, 0, 0);
+        DYX = __builtin_amdgcn_mfma_f64_16x16x4f64(ax_, bx1[ks], DYX, 0, 0, 0);
+        DYY = __builtin_amdgcn_mfma_f64_16x16x4f64(ay_, bx1[ks], DYY, 0, 0, 0);
+      }
+      // accumulator layout: register r of lane (lk, li) = quadrature row lk + 4 r of this block, cell column li
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        slab[w][0][lk + 4 * r][li] = QX[r] * DXX[r] + QY[r] * DXY[r];
+        slab[w][1][lk + 4 * r][li] = QX[r] * DYX[r] + QY[r] * DYY[r];
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) {
+        const double b0 = slab[w][0][4 * kk + lk][li], b1 = slab[w][1][4 * kk + lk][li];
+#pragma unroll
+        for (int mu = 0; mu < MTU; mu++) {
+          const double a2 = tA2[(mu * 4 * MTQ + 4 * mt + kk) * 64 + l];
+          F[0][mu] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b0, F[0][mu], 0, 0, 0);
+          F[1][mu] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b1, F[1][mu], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+      for (int mu = 0; mu < MTU; mu++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int m = 16 * mu + lk + 4 * r;
+          if (m < NU && col) out[(long)(a * NU + m) * g.Nc + c] = F[a][mu][r];
+        }
+  }
+}
+// facet terms on top of the cell term left in `out` by k_adv_cell_mfma; two lanes per cell as in k_adv_apply2
+template <int K>
+__global__ __launch_bounds__(128) void k_adv_edges2(Geo g, DevTables T, const double* __restrict__ xin,
+                                                     const double* __restrict__ qstar, double* __restrict__ out,
+                                                     double gamma, double upwind, const double* __restrict__ bsub) {
+  constexpr int NU = Dim<K>::NU;
+  const int cpb = blockDim.x >> 1, nbx2 = (g.nx + cpb - 1) / cpb;
+  const int xcd_ = blockIdx.x & 7, q_ = blockIdx.x >> 3;
+  const int jj_ = q_ / (2 * nbx2), rem_ = q_ - jj_ * 2 * nbx2;
+  const int s = rem_ / nbx2;
+  const int i = (rem_ - s * nbx2) * cpb + (threadIdx.x >> 1);
+  const int a = threadIdx.x & 1;
+  const int j = xcd_ * g.rows_xcd + jj_;
+  if (jj_ >= g.rows_xcd || j >= g.ny || i >= g.nx) return;
+  const long c = ((long)s * (g.ny + 2) + (j + 1)) * g.nx + i;
+  const long cbase = (long)a * NU * g.Nc + c;
+  double x[NU], qs[NU], F[NU];
+#pragma unroll
+  for (int m = 0; m < NU; m++) {
+    x[m] = xin[cbase + (long)m * g.Nc];
+    qs[m] = qstar[cbase + (long)m * g.Nc];
+    F[m] = out[cbase + (long)m * g.Nc];  // cell term
+  }
+#pragma unroll
+  for (int e = 0; e < 3; e++) {
+    long cn;
+    const bool has = nbr(s, e, i, j, g, cn);
+    double xn[NU];
+    if (has) {
+#pragma unroll
+      for (int m = 0; m < NU; m++) xn[m] = xin[((long)a * NU + m) * g.Nc + cn];
+    } else {
+#pragma unroll
+      for (int m = 0; m < NU; m++) xn[m] = 0.0;
+    }
+    const double* __restrict__ Po = T.ePhi[s][e];
+    const double* __restrict__ Pn = T.ePhi[1 - s][e];
+    const double na = a == 0 ? T.enx[e] : T.eny[e], sg = T.sig[s][e];
+    const double pen = T.alpha / T.elen[e];
+    const int nq = T.nqe;
+#pragma unroll 1
+    for (int q = 0; q < nq; q++) {
+      double oa = 0, ba = 0, qna = 0;
+#pragma unroll
+      for (int m = 0; m < NU; m++) {
+        const double po = Po[q * NU + m];
+        oa = fma(po, x[m], oa);
+        ba = fma(Pn[q * NU + m], xn[m], ba);
+        qna = fma(po, na * qs[m], qna);
+      }
+      const double qn = qna + pair_swap(qna);
+      const double w = T.ew[e][q];
+      const double cf = has ? w * (0.5 * sg * qn - upwind * fabs(qn)) : 0.0;
+      const double ja = oa - ba;
+      const double jna = ja * na;
+      const double jn = (jna + pair_swap(jna)) * pen * w;
+      const double va = cf * ja - jn * na;
+#pragma unroll
+      for (int m = 0; m < NU; m++) F[m] = fma(Po[q * NU + m], va, F[m]);
+    }
+  }
+  if (bsub) {
+#pragma unroll
+    for (int m = 0; m < NU; m++) out[cbase + (long)m * g.Nc] = bsub[cbase + (long)m * g.Nc] - fma(-gamma, F[m], x[m]);
+  } else {
+#pragma unroll
+    for (int m = 0; m < NU; m++) out[cbase + (long)m * g.Nc] = fma(-gamma, F[m], x[m]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // K4  element block-Jacobi:  out = cz * zin + Dinv_s * r      (Dinv: 2NU x 2NU per shape)
 // ------------------------------------------------------------------------------------------
 template <int K>
