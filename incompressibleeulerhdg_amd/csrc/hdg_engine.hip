@@ -350,7 +350,7 @@ struct Engine {
     for (int mt = 0; mt < MT; mt++) for (int kd = 0; kd < KD; kd++) tile(packed, 16 * MT, 20, Gm, mt, kd);
     return packed;
   }
-  // tables of k_adv_cell_mfma in A-operand lane order: Phi, Gx, Gy (rows = quadrature points, columns = basis
+  // tables of k_adv_mfma in A-operand lane order: Phi, Gx, Gy (rows = quadrature points, columns = basis
   // functions), then A2[m][q] = -w_q Phi[q][m] (rows = basis functions, columns = quadrature points)
   std::vector<double> pack_adv_mfma(int s_) const {
     const int nu = tab->nu, nq = tab->nqc, MTQ = (nq + 15) / 16, KSU = (nu + 3) / 4, MTU = (nu + 15) / 16;
@@ -369,6 +369,31 @@ struct Engine {
     std::vector<double> A2((size_t)nu * nq);
     for (int m = 0; m < nu; m++) for (int q = 0; q < nq; q++) A2[(size_t)m * nq + q] = -tab->cw[q] * tab->cPhi[s_][(size_t)q * nu + m];
     for (int mu = 0; mu < MTU; mu++) for (int ks = 0; ks < 4 * MTQ; ks++) tile(nu, nq, A2, mu, ks);
+    // facet tables (k_adv_mfma): edge-point rows packed 8 per edge, tile 0 = edges 0, 1, tile 1 = edge 2
+    const int nqe = tab->nqe;
+    auto erow = [&](int e, int q) { return (e < 2 ? 8 * e : 16) + q; };
+    std::vector<double> EO((size_t)32 * nu, 0.0), EQX(EO), EQY(EO);
+    for (int e = 0; e < 3; e++)
+      for (int q = 0; q < nqe; q++)
+        for (int m = 0; m < nu; m++) {
+          const double po = tab->ePhi[s_][e][(size_t)q * nu + m];
+          EO[(size_t)erow(e, q) * nu + m] = po;
+          EQX[(size_t)erow(e, q) * nu + m] = tab->enx[e] * po;
+          EQY[(size_t)erow(e, q) * nu + m] = tab->eny[e] * po;
+        }
+    for (const std::vector<double>* M : {&EO, &EQX, &EQY})
+      for (int t = 0; t < 2; t++) for (int ks = 0; ks < KSU; ks++) tile(32, nu, *M, t, ks);
+    for (int e = 0; e < 3; e++) {  // neighbour trace rows of edge e inside its tile, zero elsewhere
+      std::vector<double> EN((size_t)16 * nu, 0.0);
+      for (int q = 0; q < nqe; q++)
+        for (int m = 0; m < nu; m++) EN[(size_t)((e == 1 ? 8 : 0) + q) * nu + m] = tab->ePhi[1 - s_][e][(size_t)q * nu + m];
+      for (int ks = 0; ks < KSU; ks++) tile(16, nu, EN, 0, ks);
+    }
+    std::vector<double> ET((size_t)nu * 24, 0.0);  // test: rows m, columns (e, q) packed: 8 e + q
+    for (int e = 0; e < 3; e++)
+      for (int q = 0; q < nqe; q++)
+        for (int m = 0; m < nu; m++) ET[(size_t)m * 24 + 8 * e + q] = tab->ePhi[s_][e][(size_t)q * nu + m];
+    for (int mu = 0; mu < MTU; mu++) for (int kd = 0; kd < 6; kd++) tile(nu, 24, ET, mu, kd);
     return packed;
   }
   const double* advm[2] = {nullptr, nullptr};
@@ -421,7 +446,7 @@ struct Engine {
   void adv_apply(const double* x, const double* qstar, double* out, double gamma, const double* bsub = nullptr) {
     halo_Q(x);
     const double up = cfg.flux_upwind ? 1.0 : 0.0;
-    // k >= 3: cell term on the matrix cores, facet terms in a two-lane kernel (k_adv_cell_mfma + k_adv_edges2)
+    // k >= 3: the whole operator on the matrix cores (k_adv_mfma); HDG_NO_MFMA_ADV falls back to the per-thread kernels
     static const bool no_mfma_adv = std::getenv("HDG_NO_MFMA_ADV") != nullptr;
     if (!no_mfma_adv && cfg.degree >= 3) {
       if (!advm[0]) {
@@ -429,15 +454,9 @@ struct Engine {
         for (int sh = 0; sh < 2; sh++) advm[sh] = upload(pack_adv_mfma(sh));
       }
       const dim3 gridc(8 * g.rows_xcd * 2);
-      const int cpb = bs() / 2, nbx2 = (g.nx + cpb - 1) / cpb;
-      const dim3 gride(8 * g.rows_xcd * 2 * nbx2);
-      if (cfg.degree == 3) {
-        k_adv_cell_mfma<3><<<gridc, 256, 0, stream>>>(g, advm[0], advm[1], x, qstar, out);
-        k_adv_edges2<3><<<gride, bs(), 0, stream>>>(g, dt, x, qstar, out, gamma, up, bsub);
-      } else {
-        k_adv_cell_mfma<4><<<gridc, 256, 0, stream>>>(g, advm[0], advm[1], x, qstar, out);
-        k_adv_edges2<4><<<gride, bs(), 0, stream>>>(g, dt, x, qstar, out, gamma, up, bsub);
-      }
+      if (dt.nqe != (3 * cfg.degree + 5) / 2) throw std::string("edge quadrature size does not match the matrix-core advection kernel");
+      if (cfg.degree == 3) k_adv_mfma<3><<<gridc, 512, 0, stream>>>(g, dt, advm[0], advm[1], x, qstar, out, gamma, up, bsub);
+      else k_adv_mfma<4><<<gridc, 512, 0, stream>>>(g, dt, advm[0], advm[1], x, qstar, out, gamma, up, bsub);
       return;
     }
     // k = 3: two lanes per cell, one velocity component each (k_adv_apply2).  Measured at nx = 512, one-lane vs

@@ -581,14 +581,12 @@ __global__ __launch_bounds__(128) void k_adv_apply2(Geo g, DevTables T, const do
 }
 
 // ------------------------------------------------------------------------------------------
-// K3 on the matrix cores (k >= 3), in two launches:
-//   k_adv_cell_mfma  cell term  F_cell[m] = -sum_q w_q Phi[q,m] (Q*(q) . grad) x (q)   -> out (raw, not yet combined)
-//   k_adv_edges2     facet terms added to it, then  out = x - gamma F  (or  b - (x - gamma F))
-// Cell kernel, mapping of k_edge_lift_mfma (one wave per 16 cells, tables packed on the host in A-operand lane
-// order and staged in LDS).  Per block of 16 quadrature points: six contractions over the NU basis functions
-// (Q*_x, Q*_y = Phi q*, d_x x_a, d_y x_a = Gx / Gy x_a) as MFMA chains with the coefficient planes as B operands,
-// the pointwise product on the accumulators, a 4 KB LDS slab per wave to turn the result into a B operand, and
-// the test contraction with A2[m][q] = -w_q Phi[q][m] accumulated over the blocks.
+// K3 on the matrix cores (k >= 3): k_adv_mfma.  Mapping of k_edge_lift_mfma (one wave per 16 cells, tables packed on
+// the host in A-operand lane order -- Engine::pack_adv_mfma -- and staged in LDS once per workgroup).
+// Cell term, per block of 16 quadrature points: six contractions over the NU basis functions (Q*_x, Q*_y = Phi q*,
+// d_x x_a, d_y x_a = Gx / Gy x_a) as MFMA chains with the coefficient planes as B operands, the pointwise product on
+// the accumulators, an LDS slab per wave to turn the result into a B operand, and the test contraction with
+// A2[m][q] = -w_q Phi[q][m] accumulated over the blocks.  Facet terms: see the kernel's header comment.
 // ------------------------------------------------------------------------------------------
 template <int K>
 struct AdvMfma {
@@ -598,32 +596,77 @@ struct AdvMfma {
   static constexpr int NT1 = MTQ * KSU;            // tiles per stage-1 table
   static constexpr int NTILES = 3 * NT1 + MTU * 4 * MTQ;
 };
+// The whole operator in ONE kernel: cell term as described above, then the facet terms in the same mapping.  Edge-point rows are packed 8 per edge: tile 0 = edges 0 and 1 (rows 8 e + q), tile 1 = edge 2 (rows q).
+//   own traces / Q*.n   OX, OY = EO x_a ;  QN = EQX q*_x + EQY q*_y        (EQX/EQY = n_x / n_y * Po)
+//   neighbour traces    NBX, NBY += EN_e x_a(neighbour e)                   (EN_e: Pn rows of edge e, zero elsewhere)
+//   flux (pointwise)    v = cf (own - nbr) - pen w ((own - nbr).n) n        -> LDS slab -> B operand
+//   test                F += ET v                                            (ET[m][(e,q)] = Po_e[q][m])
+//   result              out = x - gamma F   or   b - (x - gamma F)
+// Workgroup = 8 waves sharing one LDS copy of the tables; a wave owns 16 consecutive cells per trip.
 template <int K>
-__global__ __launch_bounds__(256) void k_adv_cell_mfma(Geo g, const double* __restrict__ tabs0, const double* __restrict__ tabs1,
-                                                        const double* __restrict__ xin, const double* __restrict__ qstar,
-                                                        double* __restrict__ out) {
-  typedef AdvMfma<K> A;
-  constexpr int NU = A::NU, MTQ = A::MTQ, KSU = A::KSU, MTU = A::MTU, NT1 = A::NT1;
+struct AdvMfmaFull {
+  typedef AdvMfma<K> C;
+  static constexpr int NU = C::NU, MTQ = C::MTQ, KSU = C::KSU, MTU = C::MTU, NT1 = C::NT1;
+  static constexpr int NQE = (3 * K + 5) / 2;
+  static constexpr int OFF_EO = C::NTILES, OFF_EQX = OFF_EO + 2 * KSU, OFF_EQY = OFF_EQX + 2 * KSU;
+  static constexpr int OFF_EN = OFF_EQY + 2 * KSU, OFF_ET = OFF_EN + 3 * KSU, NTILES = OFF_ET + MTU * 6;
+  static_assert(NQE <= 8, "edge rule does not fit the 8-row packing");
+};
+template <int K>
+__global__ __launch_bounds__(512) void k_adv_mfma(Geo g, DevTables T, const double* __restrict__ tabs0,
+                                                   const double* __restrict__ tabs1, const double* __restrict__ xin,
+                                                   const double* __restrict__ qstar, double* __restrict__ out, double gamma,
+                                                   double upwind, const double* __restrict__ bsub) {
+  typedef AdvMfmaFull<K> A;
+  constexpr int NU = A::NU, MTQ = A::MTQ, KSU = A::KSU, MTU = A::MTU, NT1 = A::NT1, NQE = A::NQE;
   __shared__ double tab[A::NTILES * 64];
-  __shared__ double slab[4][2][16][16];
+  __shared__ double slab[8][2][24][16];
   const int xcd_ = blockIdx.x & 7, q_ = blockIdx.x >> 3;
   const int jj_ = q_ >> 1, s = q_ & 1;
   const int j = xcd_ * g.rows_xcd + jj_;
   if (jj_ >= g.rows_xcd || j >= g.ny) return;  // whole workgroup
   const double* __restrict__ tsrc = s == 0 ? tabs0 : tabs1;
-  for (int p = threadIdx.x; p < A::NTILES * 64; p += 256) tab[p] = tsrc[p];
+  for (int p = threadIdx.x; p < A::NTILES * 64; p += 512) tab[p] = tsrc[p];
   __syncthreads();
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63, li = l & 15, lk = l >> 4;
   const double* __restrict__ tPhi = tab;
   const double* __restrict__ tGx = tab + NT1 * 64;
   const double* __restrict__ tGy = tab + 2 * NT1 * 64;
-  const double* __restrict__ tA2 = tab + 3 * NT1 * 64;  // [MTU][4 MTQ][64]
+  const double* __restrict__ tA2 = tab + 3 * NT1 * 64;
+  const double* __restrict__ tEO = tab + A::OFF_EO * 64;
+  const double* __restrict__ tEQX = tab + A::OFF_EQX * 64;
+  const double* __restrict__ tEQY = tab + A::OFF_EQY * 64;
+  const double* __restrict__ tEN = tab + A::OFF_EN * 64;
+  const double* __restrict__ tET = tab + A::OFF_ET * 64;
+  // per-lane constants of the edge-point rows this lane holds in the accumulator layout (row = lk + 4 r)
+  double cw[2][4], cnx[2][4], cny[2][4], csg[2][4], cpen[2][4];
+  int ce[2][4];
+#pragma unroll
+  for (int t = 0; t < 2; t++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int row = lk + 4 * r, e = t == 0 ? (row >> 3) : 2, q = row & 7;
+      const bool valid = q < NQE && (t == 0 || row < 8);
+      ce[t][r] = valid ? e : -1;
+      cw[t][r] = valid ? T.ew[e][q] : 0.0;
+      cnx[t][r] = T.enx[e];
+      cny[t][r] = T.eny[e];
+      csg[t][r] = T.sig[s][e];
+      cpen[t][r] = T.alpha / T.elen[e];
+    }
+  const int gj = g.joff + j;
+  const bool has0 = s == 0 ? gj > 0 : gj < g.nyg - 1;
+  const int jn0 = s == 0 ? j - 1 : j + 1;
+  const long rowN0 = ((long)(1 - s) * (g.ny + 2) + (jn0 + 1)) * g.nx, rowN = ((long)(1 - s) * (g.ny + 2) + (j + 1)) * g.nx;
   const long rowC = ((long)s * (g.ny + 2) + (j + 1)) * g.nx;
   const int ntx = (g.nx + 15) >> 4;
-  for (int tx = w; tx < ntx; tx += 4) {
+  for (int tx = w; tx < ntx; tx += 8) {
     const int i = tx * 16 + li;
     const bool col = i < g.nx;
-    const long c = rowC + (col ? i : g.nx - 1);
+    const int ic = col ? i : g.nx - 1;
+    const bool has2 = s == 0 ? i > 0 : i < g.nx - 1;
+    const int i2 = s == 0 ? ic - 1 : ic + 1;
+    const long c = rowC + ic, cn0 = rowN0 + ic, cn1 = rowN + ic, cn2 = rowN + (has2 ? i2 : ic);
     double bq0[KSU], bq1[KSU], bx0[KSU], bx1[KSU];
 #pragma unroll
     for (int ks = 0; ks < KSU; ks++) {
@@ -639,6 +682,7 @@ __global__ __launch_bounds__(256) void k_adv_cell_mfma(Geo g, const double* __re
     for (int a = 0; a < 2; a++)
 #pragma unroll
       for (int mu = 0; mu < MTU; mu++) F[a][mu] = hdg_v4d{0, 0, 0, 0};
+    // ---- cell term
 #pragma unroll
     for (int mt = 0; mt < MTQ; mt++) {
       hdg_v4d QX = {0, 0, 0, 0}, QY = QX, DXX = QX, DXY = QX, DYX = QX, DYY = QX;
@@ -652,7 +696,6 @@ __global__ __launch_bounds__(256) void k_adv_cell_mfma(Geo g, const double* __re
         DYX = __builtin_amdgcn_mfma_f64_16x16x4f64(ax_, bx1[ks], DYX, 0, 0, 0);
         DYY = __builtin_amdgcn_mfma_f64_16x16x4f64(ay_, bx1[ks], DYY, 0, 0, 0);
       }
-      // accumulator layout: register r of lane (lk, li) = quadrature row lk + 4 r of this block, cell column li
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         slab[w][0][lk + 4 * r][li] = QX[r] * DXX[r] + QY[r] * DXY[r];
@@ -671,6 +714,65 @@ __global__ __launch_bounds__(256) void k_adv_cell_mfma(Geo g, const double* __re
       }
       __builtin_amdgcn_wave_barrier();
     }
+    // ---- facet terms: traces at the edge points
+    hdg_v4d OX[2], OY[2], QN[2], NBX[2], NBY[2];
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+      OX[t] = OY[t] = QN[t] = NBX[t] = NBY[t] = hdg_v4d{0, 0, 0, 0};
+#pragma unroll
+      for (int ks = 0; ks < KSU; ks++) {
+        const double eo = tEO[(t * KSU + ks) * 64 + l];
+        OX[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(eo, bx0[ks], OX[t], 0, 0, 0);
+        OY[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(eo, bx1[ks], OY[t], 0, 0, 0);
+        QN[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(tEQX[(t * KSU + ks) * 64 + l], bq0[ks], QN[t], 0, 0, 0);
+        QN[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(tEQY[(t * KSU + ks) * 64 + l], bq1[ks], QN[t], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < KSU; ks++) {
+      const int m = 4 * ks + lk;
+      const bool mv = m < NU;
+      const double n00 = (mv && has0) ? xin[(long)m * g.Nc + cn0] : 0.0, n01 = (mv && has0) ? xin[(long)(NU + m) * g.Nc + cn0] : 0.0;
+      const double n10 = mv ? xin[(long)m * g.Nc + cn1] : 0.0, n11 = mv ? xin[(long)(NU + m) * g.Nc + cn1] : 0.0;
+      const double n20 = (mv && has2) ? xin[(long)m * g.Nc + cn2] : 0.0, n21 = (mv && has2) ? xin[(long)(NU + m) * g.Nc + cn2] : 0.0;
+      const double e0 = tEN[(0 * KSU + ks) * 64 + l], e1 = tEN[(1 * KSU + ks) * 64 + l], e2 = tEN[(2 * KSU + ks) * 64 + l];
+      NBX[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(e0, n00, NBX[0], 0, 0, 0);
+      NBY[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(e0, n01, NBY[0], 0, 0, 0);
+      NBX[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(e1, n10, NBX[0], 0, 0, 0);
+      NBY[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(e1, n11, NBY[0], 0, 0, 0);
+      NBX[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(e2, n20, NBX[1], 0, 0, 0);
+      NBY[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(e2, n21, NBY[1], 0, 0, 0);
+    }
+    // pointwise flux on the accumulators -> slab rows 0..15 (tile 0), 16..23 (tile 1 rows 0..7)
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = lk + 4 * r, e = ce[t][r];
+        const bool has = e == 0 ? has0 : (e == 2 ? has2 : true);
+        const double wq = cw[t][r], qn = QN[t][r];
+        const double cf = has ? wq * (0.5 * csg[t][r] * qn - upwind * fabs(qn)) : 0.0;
+        const double jx = OX[t][r] - NBX[t][r], jy = OY[t][r] - NBY[t][r];
+        const double jn = (jx * cnx[t][r] + jy * cny[t][r]) * cpen[t][r] * wq;
+        const double vx = e >= 0 ? cf * jx - jn * cnx[t][r] : 0.0, vy = e >= 0 ? cf * jy - jn * cny[t][r] : 0.0;
+        if (t == 0 || row < 8) {
+          slab[w][0][16 * t + row][li] = vx;
+          slab[w][1][16 * t + row][li] = vy;
+        }
+      }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int kd = 0; kd < 6; kd++) {
+      const double b0 = slab[w][0][4 * kd + lk][li], b1 = slab[w][1][4 * kd + lk][li];
+#pragma unroll
+      for (int mu = 0; mu < MTU; mu++) {
+        const double et = tET[(mu * 6 + kd) * 64 + l];
+        F[0][mu] = __builtin_amdgcn_mfma_f64_16x16x4f64(et, b0, F[0][mu], 0, 0, 0);
+        F[1][mu] = __builtin_amdgcn_mfma_f64_16x16x4f64(et, b1, F[1][mu], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- result
 #pragma unroll
     for (int a = 0; a < 2; a++)
 #pragma unroll
@@ -678,80 +780,14 @@ __global__ __launch_bounds__(256) void k_adv_cell_mfma(Geo g, const double* __re
 #pragma unroll
         for (int r = 0; r < 4; r++) {
           const int m = 16 * mu + lk + 4 * r;
-          if (m < NU && col) out[(long)(a * NU + m) * g.Nc + c] = F[a][mu][r];
+          if (m < NU && col) {
+            const long idx = (long)(a * NU + m) * g.Nc + c;
+            const double v = fma(-gamma, F[a][mu][r], xin[idx]);
+            out[idx] = bsub ? bsub[idx] - v : v;
+          }
         }
   }
 }
-// facet terms on top of the cell term left in `out` by k_adv_cell_mfma; two lanes per cell as in k_adv_apply2
-template <int K>
-__global__ __launch_bounds__(128) void k_adv_edges2(Geo g, DevTables T, const double* __restrict__ xin,
-                                                     const double* __restrict__ qstar, double* __restrict__ out,
-                                                     double gamma, double upwind, const double* __restrict__ bsub) {
-  constexpr int NU = Dim<K>::NU;
-  const int cpb = blockDim.x >> 1, nbx2 = (g.nx + cpb - 1) / cpb;
-  const int xcd_ = blockIdx.x & 7, q_ = blockIdx.x >> 3;
-  const int jj_ = q_ / (2 * nbx2), rem_ = q_ - jj_ * 2 * nbx2;
-  const int s = rem_ / nbx2;
-  const int i = (rem_ - s * nbx2) * cpb + (threadIdx.x >> 1);
-  const int a = threadIdx.x & 1;
-  const int j = xcd_ * g.rows_xcd + jj_;
-  if (jj_ >= g.rows_xcd || j >= g.ny || i >= g.nx) return;
-  const long c = ((long)s * (g.ny + 2) + (j + 1)) * g.nx + i;
-  const long cbase = (long)a * NU * g.Nc + c;
-  double x[NU], qs[NU], F[NU];
-#pragma unroll
-  for (int m = 0; m < NU; m++) {
-    x[m] = xin[cbase + (long)m * g.Nc];
-    qs[m] = qstar[cbase + (long)m * g.Nc];
-    F[m] = out[cbase + (long)m * g.Nc];  // cell term
-  }
-#pragma unroll
-  for (int e = 0; e < 3; e++) {
-    long cn;
-    const bool has = nbr(s, e, i, j, g, cn);
-    double xn[NU];
-    if (has) {
-#pragma unroll
-      for (int m = 0; m < NU; m++) xn[m] = xin[((long)a * NU + m) * g.Nc + cn];
-    } else {
-#pragma unroll
-      for (int m = 0; m < NU; m++) xn[m] = 0.0;
-    }
-    const double* __restrict__ Po = T.ePhi[s][e];
-    const double* __restrict__ Pn = T.ePhi[1 - s][e];
-    const double na = a == 0 ? T.enx[e] : T.eny[e], sg = T.sig[s][e];
-    const double pen = T.alpha / T.elen[e];
-    const int nq = T.nqe;
-#pragma unroll 1
-    for (int q = 0; q < nq; q++) {
-      double oa = 0, ba = 0, qna = 0;
-#pragma unroll
-      for (int m = 0; m < NU; m++) {
-        const double po = Po[q * NU + m];
-        oa = fma(po, x[m], oa);
-        ba = fma(Pn[q * NU + m], xn[m], ba);
-        qna = fma(po, na * qs[m], qna);
-      }
-      const double qn = qna + pair_swap(qna);
-      const double w = T.ew[e][q];
-      const double cf = has ? w * (0.5 * sg * qn - upwind * fabs(qn)) : 0.0;
-      const double ja = oa - ba;
-      const double jna = ja * na;
-      const double jn = (jna + pair_swap(jna)) * pen * w;
-      const double va = cf * ja - jn * na;
-#pragma unroll
-      for (int m = 0; m < NU; m++) F[m] = fma(Po[q * NU + m], va, F[m]);
-    }
-  }
-  if (bsub) {
-#pragma unroll
-    for (int m = 0; m < NU; m++) out[cbase + (long)m * g.Nc] = bsub[cbase + (long)m * g.Nc] - fma(-gamma, F[m], x[m]);
-  } else {
-#pragma unroll
-    for (int m = 0; m < NU; m++) out[cbase + (long)m * g.Nc] = fma(-gamma, F[m], x[m]);
-  }
-}
-
 // ------------------------------------------------------------------------------------------
 // K4  element block-Jacobi:  out = cz * zin + Dinv_s * r      (Dinv: 2NU x 2NU per shape)
 // ------------------------------------------------------------------------------------------
