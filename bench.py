@@ -11,6 +11,13 @@ All state is resident in HBM when the timed region starts.
 Prints ONE JSON line (rank 0) with the driver's contract plus ``roofline`` (dominant kernel, HIP
 events on the engine's stream) and ``cpu_baseline`` (the numpy/scipy oracle timed on a bounded
 sample of the same workload on this box's host cores, N = 1 only).
+
+``--gpus N`` with N > 1 outside ``torch.distributed.run`` launches the N ranks itself (a child
+``python -m torch.distributed.run --nproc-per-node N bench.py ...`` started before anything touches
+the GPU) and relays rank 0's line.  ``n_gpus`` is always the number of ranks that actually ran.  With
+fewer visible devices than ranks the run is a labelled rehearsal (ranks share devices, shared-memory
+transport) and is refused beyond 4 ranks per device; an RCCL failure is an error, never a silent
+change of transport.
 """
 import argparse
 import json
@@ -36,6 +43,129 @@ def ssp2_scales(nsteps, dt, kappa, t0=0.0):
         out[n, :3] = [g(tn + ci * dt) for ci in c]
         out[n, 3] = g(tn + dt)
     return out
+
+
+def csrc_sha16():
+    """Hash of the kernel sources: PMC traffic figures are only valid for the code they were measured on."""
+    import hashlib
+
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "incompressibleeulerhdg_amd", "csrc")
+    for f in ("hdg_kernels.hpp", "hdg_engine.hip", "hdg_tables.hpp", "hdg_comm.hpp"):
+        h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` (N > 1) outside torchrun: start the N ranks as fresh processes -- before any
+    GPU call in this one -- relay rank 0's JSON line, and fail unless exactly N ranks reported."""
+    import socket
+    import subprocess
+
+    import torch  # device_count() does not initialise the GPU
+
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py: no GPU visible")
+    if args.gpus > ndev and args.gpus > 4 * ndev:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but only {ndev} device(s) visible: refusing "
+                         f"(a shared-device rehearsal is limited to 4 ranks per device)")
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
+    line = None
+    for ln in r.stdout.decode().splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if r.returncode != 0 or line is None:
+        raise SystemExit(f"bench.py: the {args.gpus}-rank run failed (exit code {r.returncode})")
+    if json.loads(line)["n_gpus"] != args.gpus:
+        raise SystemExit(f"bench.py: asked for {args.gpus} ranks, {json.loads(line)['n_gpus']} reported")
+    print(line)
+    raise SystemExit(0)
+
+
+FP64_MATRIX_PEAK_TF = 78.6  # MI355X FP64 matrix = FP64 vector peak (AMD datasheet; the guide's MFMA table has no FP64 row)
+
+
+def roofline_block(eng, args, nx, k, world):
+    """Roofline of the dominant kernel, durations from HIP events on the engine's stream (hdg_time_kernel).
+
+    An iteration of the tentative-velocity solve (55-60 % of the step) is two launches: the advection operator and
+    the hybrid preconditioner (BDM lift with the element block-Jacobi folded into the lifting tables).
+      k <= 2 (Chebyshev iteration):  k_adv_apply<K> in residual form t = b - (I - gamma F(Q*)) x  (reads x, Q*, b, writes t)
+                                     k_edge_lift<K,false,2> + fused Chebyshev step (reads t, x_n, x_{n-1}, writes x_{n+1})
+                                     4 vectors of 8 N_Q bytes each; bound: HBM.
+      k >= 3 (GMRES):                k_adv_mfma<K> (reads x, Q*, writes y) and k_edge_lift_mfma<K> (reads t, writes z) on the
+                                     matrix cores; bound: FP64 MFMA.  `achieved` counts the ALGORITHMIC flops (unpadded
+                                     contraction shapes), `mfma_util` the issued v_mfma_f64_16x16x4 (padding included).
+    Whichever of the two takes longer per launch is the dominant kernel."""
+    NQ = eng.n_cells * 2 * eng.n_u  # this rank's strip: kernel timings are per-rank launches
+    NL = eng.n_edges * eng.n_l
+    NP = eng.n_cells * eng.n_p
+    NU = eng.n_u
+    hybrid = args.tent_precond == 2
+    cheb = eng.cfg.tent_solver == 1
+    mfma = k >= 3 and not os.environ.get("HDG_NO_MFMA_ADV") and not os.environ.get("HDG_NO_MFMA_LIFT")
+    gbs = lambda b, ms: b / (ms * 1e-3) / 1e9
+    ms_triad = eng.time_kernel(8, 20)  # y = a x + b y on velocity vectors: the HBM rate this box delivers
+    triad = gbs(8.0 * 3 * NQ, ms_triad)
+    others = {}
+    for name, kid, reps, nbytes in (("k_edge_lift<K,true,0>", 5, 20, 8.0 * 2 * NQ), ("k_trace_apply<K>", 1, 50, 8.0 * 2 * NL),
+                                    ("k_backsub<K>", 3, 20, 8.0 * (NL + 2 * NQ + 2 * NP))):
+        ms = eng.time_kernel(kid, reps)
+        others[name] = dict(ms=ms, GBs=gbs(nbytes, ms), algorithmic_bytes=nbytes)
+    pmc = {}
+    try:  # HBM bytes per launch from PMC passes -- only if they were measured on THIS code and workload
+        tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        if tj.get("csrc_sha16") == csrc_sha16() and tj.get("workload") == {"nx": nx, "degree": k} and world == 1:
+            pmc = tj["kernels"]
+    except Exception:
+        pmc = {}
+    if not mfma:
+        kid_lift = (6 if hybrid else 4) if cheb else (9 if hybrid else 4)
+        ms_lift = eng.time_kernel(kid_lift, 20)
+        ms_adv = eng.time_kernel(7 if cheb else 0, 20)
+        nv_lift = ((4 if hybrid else 6) if cheb else 2)
+        nv_adv = 4 if cheb else 3
+        lift_name = (f"k_edge_lift<{k},false,{2 if hybrid else 1}>" + (" + Chebyshev step" if cheb else ""))
+        adv_name = f"k_adv_apply<{k}>" + (" (residual form b - (I - gamma F) x)" if cheb else "")
+        cand = {"lift": (lift_name, 8.0 * nv_lift * NQ, ms_lift), "adv": (adv_name, 8.0 * nv_adv * NQ, ms_adv)}
+        dom = "adv" if ms_adv >= ms_lift else "lift"
+        oth = "lift" if dom == "adv" else "adv"
+        dname, dbytes, dms = cand[dom]
+        others[cand[oth][0]] = dict(ms=cand[oth][2], GBs=gbs(cand[oth][1], cand[oth][2]), algorithmic_bytes=cand[oth][1],
+                                    traffic=pmc.get(oth))
+        return dict(bound="hbm", kernel=dname, achieved=gbs(dbytes, dms), peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=gbs(dbytes, dms) / HBM_PEAK_GBS, traffic=pmc.get(dom), algorithmic_bytes=dbytes, ms_per_launch=dms,
+                    stream_triad_GBs=triad, frac_of_triad=gbs(dbytes, dms) / triad, other_kernels=others)
+    # matrix-core kernels (k >= 3)
+    nq = {3: 36, 4: 64}[k]
+    nqe = (3 * k + 5) // 2
+    ksu, mtu, mtq = (NU + 3) // 4, (NU + 15) // 16, (nq + 15) // 16
+    n2 = 2 * NU
+    ks, mt = (n2 + 3) // 4, (n2 + 15) // 16
+    tiles = eng.n_cells / 16.0  # one wave trip per 16 cells (partial tiles of a row ignored)
+    adv_issued = (mtq * (6 * ksu + 8 * mtu) + 8 * ksu + 6 * ksu + 12 * mtu) * 2048.0 * tiles
+    adv_alg = eng.n_cells * (nq * (16.0 * NU + 8) + 3 * nqe * (14.0 * NU + 20))
+    ne = k + 2
+    lift_issued = (5 * ks + 5 * mt) * 2048.0 * tiles
+    lift_alg = eng.n_cells * (2.0 * 3 * ne * n2 * 2 + 2.0 * n2 * 3 * ne)  # own + neighbour moments, lifting
+    ms_adv = eng.time_kernel(0, 20)
+    ms_lift = eng.time_kernel(9, 20)
+    tf = lambda fl, ms: fl / (ms * 1e-3) / 1e12
+    others[f"k_edge_lift_mfma<{k}>"] = dict(ms=ms_lift, TFLOPs=tf(lift_alg, ms_lift), mfma_util=tf(lift_issued, ms_lift) / FP64_MATRIX_PEAK_TF,
+                                             GBs=gbs(8.0 * 2 * NQ, ms_lift), algorithmic_bytes=8.0 * 2 * NQ, traffic=pmc.get("lift"))
+    return dict(bound="mfma", kernel=f"k_adv_mfma<{k}>", achieved=tf(adv_alg, ms_adv), peak=FP64_MATRIX_PEAK_TF, unit="TFLOP/s",
+                frac=tf(adv_alg, ms_adv) / FP64_MATRIX_PEAK_TF, mfma_util=tf(adv_issued, ms_adv) / FP64_MATRIX_PEAK_TF,
+                algorithmic_flops=adv_alg, issued_mfma_flops=adv_issued, ms_per_launch=ms_adv, traffic=pmc.get("adv"),
+                hbm_GBs=gbs(8.0 * 3 * NQ, ms_adv), algorithmic_bytes=8.0 * 3 * NQ, stream_triad_GBs=triad, other_kernels=others)
 
 
 def cpu_baseline(degree, budget_s=20.0):
@@ -79,11 +209,16 @@ def main():
     ap.add_argument("--comm", choices=["rccl", "shm"], default="rccl", help="inter-rank transport for --gpus > 1")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args, sys.argv[1:])
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} does not match WORLD_SIZE={world}")
     dist = None
     shared_gpu = False
+    ndev = 1
     if world > 1:
         import torch
         import torch.distributed as dist_
@@ -94,9 +229,12 @@ def main():
             dist_.init_process_group("nccl")
         else:
             # rehearsal on a box with fewer GPUs than ranks: ranks share devices, rendezvous over gloo,
-            # data over the shared-memory transport (RCCL refuses duplicate devices)
+            # data over the shared-memory transport (RCCL refuses duplicate devices).  Labelled as such in the
+            # output; refused beyond 4 ranks per device (it would say nothing about scaling).
+            if ndev < 1 or world > 4 * ndev:
+                raise SystemExit(f"bench.py: {world} ranks on {ndev} visible device(s): refusing")
             shared_gpu = True
-            local_rank = local_rank % max(ndev, 1)
+            local_rank = local_rank % ndev
             torch.cuda.set_device(local_rank)
             dist_.init_process_group("gloo")
             args.comm = "shm"
@@ -146,26 +284,22 @@ def main():
 
     backend = args.comm if world > 1 else "none"
     if world > 1 and backend == "rccl":
-        # rehearse the transport in a child process first: a failure or hang costs a timeout, not the run
+        # rehearse the transport in a child process first: a failure or hang costs a timeout, not the run.
+        # A failure is an ERROR: a multi-GPU number over a different transport would be a different measurement
+        # (--comm shm asks for the host-staged transport explicitly).
         from incompressibleeulerhdg_amd.distributed import probe_transport
 
         ok_probe = probe_transport("rccl")
         if int(reduce_scalar(1.0 if ok_probe else 0.0, dist.ReduceOp.MIN)) == 0:
-            if rank == 0:
-                print("[bench] RCCL transport probe failed; using the shared-memory transport", file=sys.stderr)
-            backend = "shm"
+            raise SystemExit("bench.py: the RCCL transport probe failed on at least one rank")
     try:
         ts = build(backend)
         ok = 1
     except Exception as exc:  # noqa: BLE001
         ok, err = 0, repr(exc)
         print(f"[rank {rank}] transport '{backend}' failed: {err}", file=sys.stderr)
-    if world > 1:
-        if int(reduce_scalar(float(ok), dist.ReduceOp.MIN)) == 0:
-            if backend == "shm":
-                raise SystemExit("no working transport")
-            backend = "shm"
-            ts = build(backend)
+    if int(reduce_scalar(float(ok), dist.ReduceOp.MIN)) == 0 if world > 1 else ok == 0:
+        raise SystemExit(f"bench.py: engine construction failed (transport {backend})")
     eng = ts._engine
     mp = TaylorGreen(ts._V_Q, ts._V_p, "exponential", kappa)
     eng.set_state(ts._V_Q.interpolate(mp.Q_stationary), ts._V_p.interpolate(mp.p_stationary))
@@ -188,58 +322,11 @@ def main():
             ("tentative", "pressure", "final_pressure", "pressure_reconstruction"), sums, cnt)}
         ntot = eng.n_total
         value = ntot * args.steps / elapsed / 1e6
-        # --- roofline of the dominant kernel.  A Chebyshev iteration of the tentative-velocity solve is two
-        # launches that share ~55 % of the step (profiles/r01_i_kernel_stats_c3.csv: 28.6 % + 26.6 %):
-        #   k_adv_apply (residual form): t = b - (I - gamma F(Q*)) x; reads x, Q*, b and writes t: 4 vectors;
-        #   k_edge_lift<K,false,2> + Chebyshev step: z = t + sum_e G_e d_e(t) (BDM lift with the element
-        #     block-Jacobi folded into the lifting tables), x_{n+1} = x_n + c1 (x_n - x_{n-1}) + c2 z written over
-        #     x_{n-1}: reads t, x_n, x_{n-1}, writes x_{n+1}: 4 vectors (the additive preconditioner,
-        #     --tent-precond 1, reads one more).
-        # 8 B per entry.  Whichever takes longer per launch is reported as the dominant
-        # kernel, the other under other_kernels.  Durations from HIP events on the engine's stream.
-        NQ = eng.n_cells * 2 * eng.n_u  # this rank's strip: kernel timings below are per-rank launches
-        NL = eng.n_edges * eng.n_l
-        NP = eng.n_cells * eng.n_p
-        hybrid = args.tent_precond == 2
-        ms_lift = eng.time_kernel(6 if hybrid else 4, 20)
-        ms_adv = eng.time_kernel(7, 20)
-        ms_liftT = eng.time_kernel(5, 20)
-        ms_tr = eng.time_kernel(1, 50)
-        ms_bs = eng.time_kernel(3, 20)
-        ms_triad = eng.time_kernel(8, 20)  # y = a x + b y on velocity vectors: the HBM rate this box actually delivers
-        lift_bytes = 8.0 * (4 if hybrid else 5) * NQ
-        adv_bytes = 8.0 * 4 * NQ
-        lift_name = ("k_edge_lift<K,false,2> (BDM lift + block-Jacobi of the remainder + Chebyshev step)" if hybrid
-                     else "k_edge_lift<K,false,1> (BDM lift + block-Jacobi + Chebyshev step)")
-        adv_name = "k_adv_apply<K> (advection operator, residual form b - (I - gamma F) x)"
-        pmc = {}
-        try:  # HBM bytes per launch from the committed PMC passes (same workload, single rank only)
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            if tj["workload"] == {"nx": nx, "degree": k} and world == 1 and hybrid:
-                pmc = {"lift": tj["kernels"]["k_edge_lift<K,false,2>+cheb"]["hbm_bytes"],
-                       "adv": tj["kernels"]["k_adv_apply(+residual)"]["hbm_bytes"]}
-        except Exception:
-            pmc = {}
-        gbs = lambda b, ms: b / (ms * 1e-3) / 1e9
-        cand = {"lift": (lift_name, lift_bytes, ms_lift), "adv": (adv_name, adv_bytes, ms_adv)}
-        dom = "adv" if ms_adv >= ms_lift else "lift"
-        oth = "lift" if dom == "adv" else "adv"
-        dname, dbytes, dms = cand[dom]
-        roof = dict(bound="hbm", kernel=dname, achieved=gbs(dbytes, dms), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=gbs(dbytes, dms) / HBM_PEAK_GBS, traffic=pmc.get(dom), algorithmic_bytes=dbytes,
-                    ms_per_launch=dms, stream_triad_GBs=gbs(8.0 * 3 * NQ, ms_triad),
-                    frac_of_triad=gbs(dbytes, dms) / gbs(8.0 * 3 * NQ, ms_triad),
-                    other_kernels={
-                        cand[oth][0]: dict(ms=cand[oth][2], GBs=gbs(cand[oth][1], cand[oth][2]),
-                                           algorithmic_bytes=cand[oth][1], traffic=pmc.get(oth)),
-                        "k_edge_lift<K,true,0>": dict(ms=ms_liftT, GBs=gbs(8.0 * 2 * NQ, ms_liftT)),
-                        "k_trace_apply": dict(ms=ms_tr, GBs=gbs(8.0 * 2 * NL, ms_tr)),
-                        "k_backsub": dict(ms=ms_bs, GBs=gbs(8.0 * (NL + 2 * NQ + 2 * NP), ms_bs)),
-                    })
+        roof = roofline_block(eng, args, nx, k, world)
         line = {
             "metric": "million DOF-updates/sec (HDG-IMEX k=2, 1024^2 tri mesh)" if (nx, k) == (1024, 2)
             else f"million DOF-updates/sec (HDG-IMEX k={k}, {nx}^2 tri mesh)",
-            "value": value, "unit": "million DOF-updates/s", "n_gpus": args.gpus, "steps": args.steps,
+            "value": value, "unit": "million DOF-updates/s", "n_gpus": world, "n_devices": min(world, ndev), "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"HDG-IMEX SSP2(3,3,2) R=2 projection upwind, k={k}, {nx}x{nx} tri mesh, "

@@ -38,6 +38,7 @@ struct CommError {
 
 struct Comm {
   int rank = 0, size = 1;
+  bool failed = false;  // a collective of this rank failed: tear the communicator down without waiting for the peers
   virtual ~Comm() {}
   // send `n` doubles from slo to rank-1 and from shi to rank+1; receive the neighbours' messages
   // into rlo (from rank-1) and rhi (from rank+1).  Missing neighbours are skipped.
@@ -62,10 +63,11 @@ struct CommRccl : Comm {
     if (r != ncclSuccess) throw CommError{std::string("ncclCommInitRank: ") + ncclGetErrorString(r)};
   }
   ~CommRccl() override {
-    if (comm) ncclCommDestroy(comm);
+    // after a rank-local failure the peers may be blocked inside a collective: abort (does not wait for them)
+    if (comm) { if (failed) ncclCommAbort(comm); else ncclCommDestroy(comm); }
   }
-  static void ck(ncclResult_t r, const char* what) {
-    if (r != ncclSuccess) throw CommError{std::string(what) + ": " + ncclGetErrorString(r)};
+  void ck(ncclResult_t r, const char* what) {
+    if (r != ncclSuccess) { failed = true; throw CommError{std::string(what) + ": " + ncclGetErrorString(r)}; }
   }
   void exchange(const double* slo, double* rlo, const double* shi, double* rhi, size_t n, hipStream_t st) override {
     ck(ncclGroupStart(), "ncclGroupStart");
@@ -142,12 +144,13 @@ struct CommShm : Comm {
     // a fresh segment is zero filled by the kernel; announce this rank and wait for the others
     hdr(rank)->attached.store(1, std::memory_order_release);
     for (int r = 0; r < size; r++) wait_ge(hdr(r)->attached, 1, "peers to attach");
+    // every rank holds its mapping now: the name can go (a crashed run then leaves nothing behind in /dev/shm)
+    if (rank == 0) shm_unlink(shm_name.c_str());
     stage.resize(std::max<size_t>(std::max(cap_halo * 2, cap_gather), 64));
   }
   ~CommShm() override {
     if (base) {
       munmap(base, total);
-      if (rank == 0) shm_unlink(shm_name.c_str());
     }
   }
   void exchange(const double* slo, double* rlo, const double* shi, double* rhi, size_t n, hipStream_t st) override {

@@ -22,6 +22,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -111,7 +112,6 @@ struct Engine {
   // multigrid levels (vertex grids)
   std::vector<int> mg_n;
   std::vector<double*> mg_x, mg_b, mg_r;
-  hipGraphExec_t vcycle_graph = nullptr;  // the V-cycle is a fixed launch sequence on fixed buffers
   // stats
   double it_sum[4] = {0, 0, 0, 0};
   long it_cnt[4] = {0, 0, 0, 0};
@@ -161,6 +161,26 @@ struct Engine {
     if (!(c.dt > 0)) throw std::string("dt must be positive");
     HIPCHECK(hipSetDevice(c.device));
     HIPCHECK(hipStreamCreate(&stream));
+    // no destructor runs for a half-built object: release what has been acquired so far and rethrow
+    // (the communicator stays with the caller until construction has succeeded)
+    try {
+      construct(c);
+    } catch (...) {
+      release();
+      throw;
+    }
+  }
+  void release() {
+    for (void* p : allocs) (void)hipFree(p);
+    allocs.clear();
+    if (h_res) { (void)hipHostFree(h_res); h_res = nullptr; }
+    if (h_cgs) { (void)hipHostFree(h_cgs); h_cgs = nullptr; }
+    if (cg_ev) { (void)hipEventDestroy(cg_ev); cg_ev = nullptr; }
+    if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; }
+    delete tab;
+    tab = nullptr;
+  }
+  void construct(const hdg_config& c) {
     K = c.degree;
     s = c.nstages;
     NU = n_scalar(K + 1); NP = n_scalar(K); NL = K + 1; NE = K + 2; NX = 2 * NU + NP;
@@ -197,13 +217,7 @@ struct Engine {
     if (debug_on() && comm && comm->rank == 0)
       fprintf(stderr, "[comm] halo exchanges: velocity %ld, pressure %ld, trace %ld; all-reduces %ld; all-gathers %ld\n",
               n_halo[0], n_halo[1], n_halo[2], n_reduce, n_gather);
-    if (vcycle_graph) (void)hipGraphExecDestroy(vcycle_graph);
-    for (void* p : allocs) (void)hipFree(p);
-    if (h_res) (void)hipHostFree(h_res);
-    if (h_cgs) (void)hipHostFree(h_cgs);
-    if (cg_ev) (void)hipEventDestroy(cg_ev);
-    if (stream) (void)hipStreamDestroy(stream);
-    delete tab;
+    release();
     delete comm;
   }
 
@@ -1190,23 +1204,7 @@ struct Engine {
     k_p1_prolong_add<<<grid, 64, 0, stream>>>(nc, mg_x[lev + 1], mg_x[lev]);
     p1_smooth(lev, nsw, true);
   }
-  // The V-cycle is ~165 launches of 1-10 us kernels: launch-bound.  Capture it once into a hipGraph
-  // (fixed sequence, fixed buffers) and replay it.  Measured at C3: no gain (the cost is kernel time, not
-  // launch gaps) and rocprofv3 --kernel-trace crashes on the replay, so the graph path is opt-in
-  // (HDG_USE_GRAPH=1) and the eager path is the default.
-  void run_vcycle() {
-    if (!std::getenv("HDG_USE_GRAPH")) { vcycle(0); return; }
-    if (!vcycle_graph) {
-      hipGraph_t graph = nullptr;
-      HIPCHECK(hipStreamSynchronize(stream));
-      HIPCHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-      vcycle(0);
-      HIPCHECK(hipStreamEndCapture(stream, &graph));
-      HIPCHECK(hipGraphInstantiate(&vcycle_graph, graph, nullptr, nullptr, 0));
-      (void)hipGraphDestroy(graph);
-    }
-    HIPCHECK(hipGraphLaunch(vcycle_graph, stream));
-  }
+  void run_vcycle() { vcycle(0); }
   // z = M r for the condensed system
   void trace_precond(const double* r, double* z) {
     if (cfg.trace_precond == 0) {
@@ -1715,10 +1713,26 @@ struct Engine {
     }
   }
 
+  // Micro-benchmark of one kernel launch (bench.py's roofline probe).  Ids: 0 advection operator, 1 trace operator,
+  // 2 BDM projection, 3 back-substitution, 4 additive preconditioner + Chebyshev step, 5 transposed lift,
+  // 6 hybrid preconditioner + Chebyshev step (per-thread lift kernel), 7 advection operator in residual form,
+  // 8 stream triad on velocity vectors, 9 hybrid preconditioner alone (the GMRES path: matrix-core lift at k >= 3)
+  static constexpr int N_TIME_KERNELS = 10;
   double time_kernel(int kernel, int reps) {
-    hipEvent_t e0, e1;
-    HIPCHECK(hipEventCreate(&e0));
-    HIPCHECK(hipEventCreate(&e1));
+    if (kernel < 0 || kernel >= N_TIME_KERNELS) throw std::string("unknown kernel id");  // before any state is touched
+    // halo exchanges are switched off for the bare launches (the call is not collective); restored on EVERY exit path
+    struct Guard {
+      Engine& e;
+      hipEvent_t e0 = nullptr, e1 = nullptr;
+      explicit Guard(Engine& e_) : e(e_) { e.halo_on = false; }
+      ~Guard() {
+        e.halo_on = true;
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+      }
+    } gd(*this);
+    HIPCHECK(hipEventCreate(&gd.e0));
+    HIPCHECK(hipEventCreate(&gd.e1));
     auto launch = [&]() {
       switch (kernel) {
         case 0: adv_apply(curQ, Qstar[0], wQ1, 0.25 * cfg.dt); break;
@@ -1738,20 +1752,20 @@ struct Engine {
           break;
         case 7: adv_apply(curQ, Qstar[0], wQ1, 0.25 * cfg.dt, wQ2); break;  // residual form b - A x
         case 8: axpby(NQ, 0.5, wQ2, 0.25, wQ1); break;  // stream triad y = a x + b y on velocity vectors: 3 passes of 8 N_Q bytes
+        case 9:  // hybrid preconditioner without the Chebyshev epilogue (what GMRES applies; k >= 3: k_edge_lift_mfma)
+          ensure_dinv(1 % s, 0.25 * cfg.dt);
+          bdm_hybrid(wQ2, wQ1, hybg0[1 % s], hybg1[1 % s]);
+          break;
         default: throw std::string("unknown kernel id");
       }
     };
-    halo_on = false;
     for (int i = 0; i < 3; i++) launch();
-    HIPCHECK(hipEventRecord(e0, stream));
+    HIPCHECK(hipEventRecord(gd.e0, stream));
     for (int i = 0; i < reps; i++) launch();
-    HIPCHECK(hipEventRecord(e1, stream));
-    halo_on = true;
-    HIPCHECK(hipEventSynchronize(e1));
+    HIPCHECK(hipEventRecord(gd.e1, stream));
+    HIPCHECK(hipEventSynchronize(gd.e1));
     float ms = 0;
-    HIPCHECK(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
+    HIPCHECK(hipEventElapsedTime(&ms, gd.e0, gd.e1));
     return (double)ms / reps;
   }
 };
@@ -1778,7 +1792,7 @@ static std::string g_create_error;
     _le = hipGetLastError();                                                  \
     if (_le != hipSuccess) { (h)->err = std::string("HIP launch: ") + hipGetErrorString(_le); return HDG_ERR_HIP; } \
     return HDG_OK;                                                            \
-  } catch (const hdg::HipError& e) { (h)->err = e.msg; return HDG_ERR_HIP;    \
+  } catch (const hdg::HipError& e) { (h)->err = e.msg; if (E.comm) E.comm->failed = true; return HDG_ERR_HIP; \
   } catch (const hdg::NotConverged& e) { (h)->err = e.msg; return HDG_ERR_NOT_CONVERGED; \
   } catch (const hdg::CommError& e) { (h)->err = e.msg; return HDG_ERR_COMM;       \
   } catch (const std::string& e) { (h)->err = e; return HDG_ERR_ARG;          \
@@ -1804,14 +1818,14 @@ static int create_impl(const hdg_config* cfg, int rank, int nranks, int backend,
   *out = nullptr;
   try {
     if (hipSetDevice(cfg->device) != hipSuccess) { g_create_error = "hipSetDevice failed (no GPU?)"; return HDG_ERR_HIP; }
-    hdg::Comm* comm = nullptr;
+    std::unique_ptr<hdg::Comm> comm;  // owned here until the engine has been built
     if (nranks == 1 && std::getenv("HDG_FORCE_RCCL")) {
       // smoke path: exercise RCCL initialisation, all-reduce and all-gather with a 1-rank communicator
       ncclUniqueId id;
       if (ncclGetUniqueId(&id) != ncclSuccess) { g_create_error = "ncclGetUniqueId failed"; return HDG_ERR_COMM; }
-      comm = new hdg::CommRccl(0, 1, reinterpret_cast<const char*>(&id));
-    } else if (nranks == 1) comm = new hdg::Comm();
-    else if (backend == HDG_COMM_RCCL) { if (!token) return HDG_ERR_ARG; comm = new hdg::CommRccl(rank, nranks, token); }
+      comm.reset(new hdg::CommRccl(0, 1, reinterpret_cast<const char*>(&id)));
+    } else if (nranks == 1) comm.reset(new hdg::Comm());
+    else if (backend == HDG_COMM_RCCL) { if (!token) return HDG_ERR_ARG; comm.reset(new hdg::CommRccl(rank, nranks, token)); }
     else if (backend == HDG_COMM_SHM) {
       if (!token) return HDG_ERR_ARG;
       const int k = cfg->degree;
@@ -1819,9 +1833,10 @@ static int create_impl(const hdg_config* cfg, int rank, int nranks, int backend,
       const size_t P = ((size_t)cfg->nx + 1 + 15) / 16 * 16;
       const size_t cap_halo = std::max<size_t>(2 * nu * 2 * cfg->nx, 3 * (size_t)(k + 1) * P);
       const size_t cap_gather = ((size_t)cfg->ny / nranks + 1) * ((size_t)cfg->nx + 1);
-      comm = new hdg::CommShm(rank, nranks, token, cap_halo, cap_gather);
+      comm.reset(new hdg::CommShm(rank, nranks, token, cap_halo, cap_gather));
     } else return HDG_ERR_ARG;
-    hdg::Engine* e = new hdg::Engine(*cfg, comm);
+    hdg::Engine* e = new hdg::Engine(*cfg, comm.get());
+    comm.release();  // the engine owns it from here (~Engine)
     *out = new hdg_handle{e, ""};
     return HDG_OK;
   } catch (const hdg::HipError& e) { g_create_error = e.msg; return HDG_ERR_HIP;

@@ -1,6 +1,6 @@
 """Worker of tests/test_gpu_multirank.py: one rank of a strip-partitioned HDG-IMEX run.
 
-usage: mp_strip_worker.py RANK NRANKS TOKEN K NX NSTEPS OUTFILE [unsplit]
+usage: mp_strip_worker.py RANK NRANKS TOKEN K NX NSTEPS OUTFILE [unsplit] [badtimer]
 """
 import os
 import sys
@@ -13,7 +13,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def main():
     rank, nranks, token, k, nx, nsteps, out = (int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4]),
                                                int(sys.argv[5]), int(sys.argv[6]), sys.argv[7])
-    unsplit = len(sys.argv) > 8 and sys.argv[8] == "unsplit"
+    unsplit = "unsplit" in sys.argv[8:]
+    badtimer = "badtimer" in sys.argv[8:]
     from incompressibleeulerhdg_amd import _lib
     from incompressibleeulerhdg_amd.mesh import UnitSquareMesh
     from incompressibleeulerhdg_amd.model_problems import TaylorGreen
@@ -23,6 +24,15 @@ def main():
     ts = IncompressibleEulerHDGIMEXSSP2_332(UnitSquareMesh(nx, nx), k, dt, use_projection_method=not unsplit,
                                             n_richardson=2, rank=rank, nranks=nranks, comm_backend="shm", comm_token=token)
     mp = TaylorGreen(ts._V_Q, ts._V_p)
+    if badtimer:
+        # a failed micro-benchmark call (unknown kernel id) must leave the halo exchanges switched ON: the step
+        # below then still matches the single-rank run (hdg_time_kernel is not collective: no peer is involved)
+        try:
+            ts._engine.time_kernel(99, 1)
+            raise SystemExit("time_kernel(99) did not fail")
+        except _lib.HDGError:
+            pass
+        assert ts._engine.time_kernel(8, 2) > 0
     Q, p = ts.solve(*mp.initial_condition(), None, mp.f_rhs(), nsteps * dt, fused=True)
     lam = ts._engine.get_field(_lib.HDG_STATE_CURRENT, Q=False, p=False)[2]
     Qe, pe = mp.solution(nsteps * dt, ts._engine.integrate_pressure)

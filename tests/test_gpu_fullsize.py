@@ -48,8 +48,11 @@ def test_operator_properties_at_baseline_size(hip_lib, k, nx):
     assert np.max(np.abs(e.get_field(1, p=False, lam=False)[0] - x)) < 1e-12 * np.max(np.abs(x))
 
 
-@pytest.mark.parametrize("k,nx,nsteps", [(1, 256, 3), (2, 1024, 2)])
+@pytest.mark.parametrize("k,nx,nsteps", [(1, 256, 3), (2, 1024, 2), (3, 512, 1), (4, 256, 1), (4, 2048, 1)])
 def test_timestep_properties_at_baseline_size(hip_lib, k, nx, nsteps):
+    """C2 (k=1, 256^2), C3 (k=2, 1024^2) and C5 (k=4, 2048^2: 541 M unknowns on ONE MI355X) of BASELINE.json, plus the
+    matrix-core kernels at k = 3, 4 on meshes with many tiles: the error against the exact vortex catches a wrong
+    stencil / neighbour index at sizes the oracle cannot reach."""
     from incompressibleeulerhdg_amd import _lib
 
     ts, mp = _stepper(k, nx)
@@ -70,3 +73,32 @@ def test_timestep_properties_at_baseline_size(hip_lib, k, nx, nsteps):
     sums, cnt = e.iteration_stats()
     its = sums / np.maximum(cnt, 1)
     assert its[0] < 70 and np.all(its[1:] < 20), its
+
+
+@pytest.mark.parametrize("proj,nsteps", [(True, 2), (False, 1)])
+def test_implicit_timestep_properties_at_C4_size(hip_lib, proj, nsteps):
+    """BASELINE C4: IncompressibleEulerHDGImplicit, k = 3, 512 x 512 (hdg_implicit.py:92-190), Chorin projection and
+    the monolithic (u, phi, lambda) solve, on one GPU.  Size-independent properties: zero-mean pressure, error
+    against the exact vortex (first order in dt: the error of one or two steps is O(dt^2)), iteration bounds."""
+    from incompressibleeulerhdg_amd.mesh import UnitSquareMesh
+    from incompressibleeulerhdg_amd.model_problems import TaylorGreen
+    from incompressibleeulerhdg_amd.timesteppers import IncompressibleEulerHDGImplicit
+
+    k, nx = 3, 512
+    dt = 0.25 / nx
+    ts = IncompressibleEulerHDGImplicit(UnitSquareMesh(nx, nx), k, dt, use_projection_method=proj)
+    mp = TaylorGreen(ts._V_Q, ts._V_p, "exponential", 0.5)
+    e = ts._engine
+    Q, p = ts.solve(*mp.initial_condition(), None, mp.f_rhs(), nsteps * dt)
+    assert abs(e.integrate_pressure(p.dat.data)) < 1e-11
+    Qe, pe = mp.solution(nsteps * dt, e.integrate_pressure)
+    eq, ep = e.l2_norms(Q.dat.data - Qe.dat.data, p.dat.data - pe.dat.data)
+    nq, _ = e.l2_norms(Qe.dat.data, pe.dat.data)
+    # time error of the first-order scheme after n steps ~ n dt^2 |Q_tt| ~ 1e-7; the pressure is first order in dt
+    assert eq < 1e-5 * nq and ep < 1e-2, (eq / nq, ep)
+    assert 0 < ts.niter_tentative.value < 120, ts.niter_tentative.value
+    if proj:
+        assert 0 < ts.niter_pressure.value < 25, ts.niter_pressure.value
+        # the projection step leaves a velocity whose BDM projection is (almost) itself: normal jumps are O(dt)
+        Qn = Q.dat.data
+        assert np.max(np.abs(e.project_bdm_nodal(Qn) - Qn)) < 1e-3 * np.max(np.abs(Qn))

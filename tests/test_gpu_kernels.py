@@ -16,11 +16,23 @@ RTOL = 1e-11
 CASES = [(1, 4), (1, 7), (2, 6), (3, 4), (4, 3)]
 
 
+_DISC = {}
+
+
+def _disc(nx, k):
+    """The oracle's discretisation (read-only in these tests; building one takes 15-30 s at k >= 3, nx ~ 20)."""
+    from oracle.hdg_oracle import HDGDiscretisation
+
+    if (nx, k) not in _DISC:
+        _DISC[(nx, k)] = HDGDiscretisation(nx, k)
+    return _DISC[(nx, k)]
+
+
 def _setup(k, nx, **kw):
     from incompressibleeulerhdg_amd._lib import Engine
-    from oracle.hdg_oracle import HDGDiscretisation, TABLEAUX
+    from oracle.hdg_oracle import TABLEAUX
 
-    d = HDGDiscretisation(nx, k)
+    d = _disc(nx, k)
     tb = TABLEAUX["imex_ssp2_332"]
     e = Engine(nx=nx, degree=k, dt=0.25 / nx, nstages=3, a_expl=tb["a_expl"], a_impl=tb["a_impl"],
                b_expl=tb["b_expl"], b_impl=tb["b_impl"], c_expl=tb["c_expl"], **kw)
@@ -163,7 +175,7 @@ def test_time_kernel_ids_and_errors(hip_lib):
         d, e = _setup(2, 16, tent_precond=tp)
         rng = np.random.default_rng(5)
         e.set_state(rng.standard_normal(e.shape_Q), rng.standard_normal(e.shape_p))
-        for kid in range(9):
+        for kid in range(10):
             ms = e.time_kernel(kid, 3)
             assert 0.0 < ms < 50.0, (tp, kid, ms)
         with pytest.raises(_lib.HDGError):
@@ -179,3 +191,24 @@ def test_project_bdm_matrix_core_kernel_tiles(hip_lib, k, nx):
     rng = np.random.default_rng(11)
     Q = rng.standard_normal(e.shape_Q)
     assert _relerr(e.project_bdm_nodal(Q), d.project_bdm(Q)) < RTOL
+
+
+@pytest.mark.parametrize("flux", ["upwind", "centered"])
+@pytest.mark.parametrize("k,nx", [(3, 20), (4, 18)])
+def test_advection_matrix_core_kernel_tiles(hip_lib, k, nx, flux):
+    """k_adv_mfma is the default advection operator at k >= 3 (BASELINE C4 / C5).  One wave owns 16 consecutive
+    cells: nx = 20 / 18 gives a full tile plus a partial one per row (columns i >= 16, the has2 / column clamps)
+    and several rows per XCD band, so the rowN / rowN0 neighbour indexing meets the oracle's assembled f_impl
+    (hdg_imex.py:313-331) for both fluxes -- not just linearity, which a wrong neighbour index would pass."""
+    d, e = _setup(k, nx, flux=flux)
+    rng = np.random.default_rng(12)
+    Qstar = d.project_bdm(rng.standard_normal(e.shape_Q))
+    x = rng.standard_normal(e.shape_Q)
+    gamma = 0.3 / nx
+    F = d.assemble_f_impl(Qstar, flux)
+    ref = x.ravel() - gamma * spla.spsolve(d.MQ.tocsc(), F @ x.ravel())
+    got = e.apply_advection(Qstar, x, gamma)
+    assert _relerr(got.ravel(), ref) < 5e-11
+    # the operator part alone (the identity would hide a small relative error in F): (x - y) / gamma = M^-1 F x
+    Fx = (x.ravel() - ref) / gamma
+    assert _relerr((x.ravel() - got.ravel()) / gamma, Fx) < 1e-9

@@ -100,3 +100,45 @@ def test_strip_partition_unsplit(hip_lib, tmp_path):
     Q1, p1 = ts.solve(*mp.initial_condition(), None, mp.f_rhs(), dt, fused=True)
     rel = lambda a, b: np.max(np.abs(a - b)) / np.max(np.abs(b))
     assert rel(Q, Q1.dat.data) < 2e-8 and rel(p, p1.dat.data) < 2e-8
+
+
+def test_failed_time_kernel_leaves_halos_on(hip_lib, tmp_path):
+    """hdg_time_kernel switches the halo exchanges off while it launches bare kernels; an unknown id (or a HIP
+    error) must not leave them off -- every later stencil operator would silently read stale ghost rows."""
+    from incompressibleeulerhdg_amd.mesh import UnitSquareMesh
+    from incompressibleeulerhdg_amd.model_problems import TaylorGreen
+    from incompressibleeulerhdg_amd.timesteppers import IncompressibleEulerHDGIMEXSSP2_332
+
+    k, nx = 2, 8
+    parts = _run_ranks(2, k, nx, 1, tmp_path, extra=("badtimer",))
+    Q, p, lam = _assemble(parts, k, nx)
+    dt = 0.25 / nx
+    ts = IncompressibleEulerHDGIMEXSSP2_332(UnitSquareMesh(nx, nx), k, dt, use_projection_method=True, n_richardson=2)
+    mp = TaylorGreen(ts._V_Q, ts._V_p)
+    Q1, p1 = ts.solve(*mp.initial_condition(), None, mp.f_rhs(), dt, fused=True)
+    rel = lambda a, b: np.max(np.abs(a - b)) / np.max(np.abs(b))
+    assert rel(Q, Q1.dat.data) < 2e-8 and rel(p, p1.dat.data) < 2e-8
+
+
+def test_bench_self_launch_reports_the_ranks_that_ran(hip_lib):
+    """`python bench.py --gpus N` outside torchrun starts the N ranks itself and reports n_gpus = ranks that ran.
+    On a box with fewer devices than ranks the run is a labelled shared-device rehearsal, refused beyond 4 ranks
+    per device (never a 1-rank number printed as N)."""
+    import json
+
+    import torch
+
+    root = os.path.dirname(HERE)
+    ndev = torch.cuda.device_count()
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--nx", "64", "--degree", "1", "--steps", "1",
+           "--warmup", "1", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    line = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["n_devices"] == min(2, ndev)
+    assert ("rehearsal" in line["config"]["parallelism"]) == (ndev < 2)
+    assert line["value"] > 0 and line["roofline"]["frac"] > 0
+    if ndev * 4 < 8:
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--nx", "64", "--degree", "1",
+                            "--steps", "1", "--no-cpu-baseline"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        assert r.returncode != 0 and not [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]

@@ -128,7 +128,7 @@ def test_taylor_green_error_norms_match_oracle(hip_lib):
     assert eq < 2e-3 and ep < 2e-2
 
 
-@pytest.mark.parametrize("k,nx", [(1, 8), (2, 4)])
+@pytest.mark.parametrize("k,nx", [(1, 8), (2, 4), (3, 4), (3, 6), (4, 3)])
 def test_hdg_implicit_projection(hip_lib, k, nx):
     from incompressibleeulerhdg_amd.mesh import UnitSquareMesh
     from incompressibleeulerhdg_amd.model_problems import TaylorGreen
@@ -190,7 +190,7 @@ def test_unsplit_stage_solve(hip_lib, k, nx, tableau):
         mp = TaylorGreen(ts._V_Q, ts._V_p)
 
 
-@pytest.mark.parametrize("k,nx,dt", [(1, 8, 0.02), (1, 16, 0.05)])
+@pytest.mark.parametrize("k,nx,dt", [(1, 8, 0.02), (1, 16, 0.05), (2, 6, 0.04), (3, 4, 0.0625), (3, 6, 0.04)])
 def test_hdg_implicit_monolithic(hip_lib, k, nx, dt):
     """BASELINE config C1 with the projection method OFF (hdg_implicit.py:151-186)."""
     from incompressibleeulerhdg_amd.mesh import UnitSquareMesh
@@ -228,3 +228,72 @@ def test_large_implicit_weight_matches_oracle(hip_lib, tableau, cfl):
         assert _relerr(a, b) < TOL, name
     sums, cnt = ts._engine.iteration_stats()
     assert 0 < sums[0] / cnt[0] < 400
+
+
+def _smooth_random_fields(seed):
+    """Random smooth data (a few Fourier modes with seeded coefficients).  Unlike the Taylor-Green vortex -- for
+    which (Q.grad)Q + grad p vanishes identically, so a timestep test is blind to the implicit tableau weights
+    (SURVEY.md section 8c caveat, App. C-2) -- the velocity is neither divergence free nor tangential on the
+    boundary, the pressure is unrelated to it, and the forcing is time dependent and not a gradient."""
+    rng = np.random.default_rng(seed)
+    cQ = rng.standard_normal((2, 3, 3, 2))
+    cP = rng.standard_normal((3, 3))
+    cF = rng.standard_normal((2, 3, 3, 2))
+
+    def modes(c, x, y):
+        out = 0.0
+        for a in range(3):
+            for b in range(3):
+                out = out + c[a, b, 0] * np.sin((a + 1) * np.pi * x + 0.3 * b) * np.cos(b * np.pi * y + 0.2 * a) \
+                    + c[a, b, 1] * np.cos(a * np.pi * x - 0.4) * np.sin((b + 1) * np.pi * y + 0.1)
+        return out / 3.0
+
+    Q0 = lambda x, y: (modes(cQ[0], x, y), modes(cQ[1], x, y))
+    p0 = lambda x, y: sum(cP[a, b] * np.cos(a * np.pi * x) * np.cos(b * np.pi * y) for a in range(3) for b in range(3)) / 3.0
+    f = lambda t: (lambda x, y: (np.cos(3.0 * t) * modes(cF[0], x, y) + t * y, (1.0 + np.sin(2.0 * t)) * modes(cF[1], x, y) - x * x))
+    return Q0, p0, f
+
+
+@pytest.mark.parametrize("k,nx,tableau,R", [(1, 6, "imex_ssp2_332", 2), (2, 5, "imex_ssp2_332", 2), (2, 4, "imex_ars3_443", 1),
+                                            (1, 6, "imex_ssp3_433", 2), (3, 4, "imex_ars2_232", 2), (1, 5, "imex_implicit", 2)])
+def test_whole_step_on_random_smooth_data(hip_lib, k, nx, tableau, R):
+    """Whole-timestep parity on data for which the implicit terms do NOT cancel: every implicit / explicit tableau
+    weight, the Richardson iteration, the pressure-reconstruction right-hand side with its boundary term and the
+    nodal (non-separable) forcing path all change the answer here."""
+    from incompressibleeulerhdg_amd import _lib
+    from incompressibleeulerhdg_amd.mesh import UnitSquareMesh
+    from oracle import hdg_oracle as orc
+
+    dt = 0.25 / nx
+    nsteps = 2
+    Q0, p0, f = _smooth_random_fields(20241104 + 7 * k + nx)
+    for fused in (False, True):
+        ts = _classes()[tableau](UnitSquareMesh(nx, nx), k, dt, use_projection_method=True, n_richardson=R)
+        Q, p = ts.solve(Q0, p0, None, f, nsteps * dt, fused=fused)
+        lam = ts._engine.get_field(_lib.HDG_STATE_CURRENT, Q=False, p=False)[2]
+        if not fused:
+            d = orc.HDGDiscretisation(nx, k)
+            o = orc.OracleHDGIMEX(d, dt, tableau, n_richardson=R)
+            oQ, op = o.solve(d.interpolate_velocity(Q0), d.interpolate_pressure(p0),
+                             lambda t: d.interpolate_velocity(f(t)), nsteps * dt)
+            # the data really exercises the implicit terms: the step changes the velocity at O(dt)
+            assert _relerr(oQ, d.interpolate_velocity(Q0)) > 1e-3
+        assert _relerr(Q.dat.data, oQ) < TOL and _relerr(p.dat.data, op) < TOL and _relerr(lam, o.lam) < TOL
+        sQ, sp_, sl = ts._engine.get_field(ts.nstages - 1)
+        assert _relerr(sQ, o.stage_Q[-1]) < TOL and _relerr(sp_, o.stage_p[-1]) < TOL and _relerr(sl, o.stage_l[-1]) < TOL
+
+
+@pytest.mark.parametrize("k,nx,proj", [(2, 5, True), (3, 4, True), (1, 6, False)])
+def test_hdg_implicit_on_random_smooth_data(hip_lib, k, nx, proj):
+    from incompressibleeulerhdg_amd.mesh import UnitSquareMesh
+    from incompressibleeulerhdg_amd.timesteppers import IncompressibleEulerHDGImplicit
+    from oracle import hdg_oracle as orc
+
+    dt = 0.25 / nx
+    Q0, p0, f = _smooth_random_fields(99 + k)
+    ts = IncompressibleEulerHDGImplicit(UnitSquareMesh(nx, nx), k, dt, use_projection_method=proj)
+    Q, p = ts.solve(Q0, p0, None, f, 2 * dt)
+    d = orc.HDGDiscretisation(nx, k)
+    oQ, op = orc.OracleHDGImplicit(d, dt, use_projection_method=proj).solve(
+        d.interpolate_velocity(Q0), d.interpolate_pressure(p0), lambda t: d.interpolate_velocity(f(t)), 2 * dt)
+    assert _relerr(Q.dat.data, oQ) < TOL and _relerr(p.dat.data, op) < TOL
