@@ -312,11 +312,11 @@ struct Engine {
   // consistent copies consistent.)
   bool halo_on = true;  // switched off while timing bare kernel launches (hdg_time_kernel is not collective)
   long n_halo[3] = {0, 0, 0}, n_reduce = 0, n_gather = 0;  // communication census (HDG_DEBUG, printed at destruction)
-  void halo_rows(double* v, long plane_stride, int row_len, int nplanes) {
+  void halo_rows(double* v, long plane_stride, int row_len, int nplanes, int kind) {
     if (comm->size == 1 || !halo_on) return;
     const long n = (long)nplanes * row_len;
     const int nb = vec_blocks(n);
-    n_halo[row_len == g.P ? 2 : (nplanes == NP * 2 ? 1 : 0)]++;
+    n_halo[kind]++;
     // 3 launches per exchange: pack both rows, neighbour send/recv, unpack both rows
     const int nbh = std::min(nb, 256);
     k_pack_rows<<<dim3(nbh, 2), 256, 0, stream>>>(v, plane_stride, row_len, nplanes, 1, g.ny, hb_slo, hb_shi);
@@ -324,9 +324,10 @@ struct Engine {
     k_unpack_rows<<<dim3(nbh, 2), 256, 0, stream>>>(v, plane_stride, row_len, nplanes, comm->rank > 0 ? 0 : -1,
                                                     comm->rank < comm->size - 1 ? g.ny + 1 : -1, hb_rlo, hb_rhi);
   }
-  void halo_Q(const double* v) { halo_rows(const_cast<double*>(v), (long)(g.ny + 2) * g.nx, g.nx, 2 * NU * 2); }
-  void halo_P(const double* v) { halo_rows(const_cast<double*>(v), (long)(g.ny + 2) * g.nx, g.nx, NP * 2); }
-  void halo_L(const double* v) { halo_rows(const_cast<double*>(v), g.G, g.P, 3 * NL); }
+  // velocity: component-pair layout -> a row of one (mode, shape) plane is 2 nx doubles
+  void halo_Q(const double* v) { halo_rows(const_cast<double*>(v), 2L * (g.ny + 2) * g.nx, 2 * g.nx, NU * 2, 0); }
+  void halo_P(const double* v) { halo_rows(const_cast<double*>(v), (long)(g.ny + 2) * g.nx, g.nx, NP * 2, 1); }
+  void halo_L(const double* v) { halo_rows(const_cast<double*>(v), g.G, g.P, 3 * NL, 2); }
 
   // ---- MFMA lift (k >= 3): tables in A-operand lane order for k_edge_lift_mfma.  Tile (mt, ks) of a matrix M:
   // 64 doubles, entry l = M[16 mt + l % 16][4 ks + l / 16] (zero outside M).  Order: W (2 M-tiles), N'_0..2, G.
@@ -341,17 +342,22 @@ struct Engine {
       }
     };
     std::vector<double> packed;
+    // The kernel walks the velocity dofs in memory order kappa = 2m + d (component-pair layout); the tables
+    // are indexed n = d*nu + m: kap[n] is the position of table column / row n in the packed matrices.
+    const int nu_ = tab->nu;
+    std::vector<int> kap(n2);
+    for (int n = 0; n < n2; n++) kap[n] = 2 * (n % nu_) + n / nu_;
     // W: rows (e, a) packed as tile 0 = edges 0, 1, tile 1 = edge 2;  W = -N[s][e]
     std::vector<double> W((size_t)32 * n2, 0.0);
     for (int e = 0; e < 3; e++)
       for (int a = 0; a < ne; a++)
-        for (int n = 0; n < n2; n++) W[(size_t)((e < 2 ? e * ne + a : 16 + a)) * n2 + n] = -tab->N[s_][e][a * n2 + n];
+        for (int n = 0; n < n2; n++) W[(size_t)((e < 2 ? e * ne + a : 16 + a)) * n2 + kap[n]] = -tab->N[s_][e][a * n2 + n];
     for (int mt = 0; mt < 2; mt++) for (int ks = 0; ks < KS; ks++) tile(packed, 32, n2, W, mt, ks);
     // N'_e = N[1 - s][e], rows at their position inside the tile
     for (int e = 0; e < 3; e++) {
       std::vector<double> Np((size_t)16 * n2, 0.0);
       for (int a = 0; a < ne; a++)
-        for (int n = 0; n < n2; n++) Np[(size_t)((e == 1 ? ne : 0) + a) * n2 + n] = tab->N[1 - s_][e][a * n2 + n];
+        for (int n = 0; n < n2; n++) Np[(size_t)((e == 1 ? ne : 0) + a) * n2 + kap[n]] = tab->N[1 - s_][e][a * n2 + n];
       for (int ks = 0; ks < KS; ks++) tile(packed, 16, n2, Np, 0, ks);
     }
     // G: columns = packed moments, K index q: q < 12 -> tile 0 row q, q >= 12 -> tile 1 row q - 12
@@ -359,7 +365,7 @@ struct Engine {
     for (int e = 0; e < 3; e++)
       for (int a = 0; a < ne; a++) {
         const int q = e < 2 ? e * ne + a : 12 + a;
-        for (int n = 0; n < n2; n++) Gm[(size_t)n * 20 + q] = Out[e][(size_t)n * ne + a];
+        for (int n = 0; n < n2; n++) Gm[(size_t)kap[n] * 20 + q] = Out[e][(size_t)n * ne + a];
       }
     for (int mt = 0; mt < MT; mt++) for (int kd = 0; kd < KD; kd++) tile(packed, 16 * MT, 20, Gm, mt, kd);
     return packed;
@@ -586,9 +592,12 @@ struct Engine {
     }
   }
   // ownership mask for a vector of length n (cell-type or trace-type row structure)
-  enum { KC = 1, KL = 2 };  // row structure of a vector: cell-type (velocity, pressure) or trace-type
+  // row structure of a vector: cell-type (pressure, per-cell scalars), trace-type, velocity (component-pair layout:
+  // a row of a plane holds 2 nx doubles)
+  enum { KC = 1, KL = 2, KQ = 3 };
   RowMask mask_for(int kind) const {
     if (kind == KL) return RowMask{g.P, g.ny + 2, 1, g.nyc};
+    if (kind == KQ) return RowMask{2 * g.nx, g.ny + 2, 1, g.ny};
     return RowMask{g.nx, g.ny + 2, 1, g.ny};
   }
   // dots of w against nv vectors over the OWNED entries, summed over ranks (host result); one sync
@@ -782,7 +791,7 @@ struct Engine {
     while (true) {
       adv_apply(x, qstar, t, gamma, b);    // t = b - A x  (residual fused into the operator kernel)
       tent_precond(didx, t, w);
-      double beta = std::sqrt(dot(NQ, w, w, KC));
+      double beta = std::sqrt(dot(NQ, w, w, KQ));
       if (beta0 < 0) beta0 = beta;
       if (beta_first) *beta_first = beta;
       if (beta_last) *beta_last = beta;
@@ -804,7 +813,7 @@ struct Engine {
           // pointer list = V_0..V_j followed by w: gather through a small staging array
           std::vector<const double*> ptrs(gm_V.begin(), gm_V.begin() + j + 1);
           ptrs.push_back(w);
-          multidot(NQ, w, ptrs, h.data(), KC);
+          multidot(NQ, w, ptrs, h.data(), KQ);
         }
         double ww = h[j + 1], s2 = 0.0;
         for (int l = 0; l <= j; l++) s2 += h[l] * h[l];
@@ -818,7 +827,7 @@ struct Engine {
         } else {
           // severe cancellation: orthogonalise explicitly and measure the norm (safe path)
           k_gs_update<MAXV><<<nvb, 256, 0, stream>>>(NQ, w, d_gmV, hc, j + 1, 1.0, gm_V[j + 1]);
-          hn = std::sqrt(dot(NQ, gm_V[j + 1], gm_V[j + 1], KC));
+          hn = std::sqrt(dot(NQ, gm_V[j + 1], gm_V[j + 1], KQ));
           if (hn > 0) axpby(NQ, 0.0, w, 1.0 / hn, gm_V[j + 1]);
         }
         for (int l = 0; l <= j; l++) H[(size_t)l * m + j] = h[l];
@@ -976,7 +985,7 @@ struct Engine {
       lo = ch_lmin[didx]; hi = ch_lmax[didx];
       adv_apply(x, qstar, wQ2, gamma, b);
       tent_precond(didx, wQ2, wQ1);
-      beta0 = beta = std::sqrt(dot(NQ, wQ1, wQ1, KC));
+      beta0 = beta = std::sqrt(dot(NQ, wQ1, wQ1, KQ));
       if (!(beta0 == beta0)) throw NotConverged{"Chebyshev: NaN residual"};
       if (beta0 == 0.0) return 0;
     }
@@ -1041,7 +1050,7 @@ struct Engine {
       k++;
       its++;
       if (check) {
-        double nz = cell_norm ? std::sqrt(dot(g.Nc, cell_ss, ones_c, KC)) : std::sqrt(dot(NQ, z, z, KC));
+        double nz = cell_norm ? std::sqrt(dot(g.Nc, cell_ss, ones_c, KC)) : std::sqrt(dot(NQ, z, z, KQ));
         if (!(nz == nz)) throw NotConverged{"Chebyshev: NaN residual"};
         if (debug_on()) fprintf(stderr, "[cheb]   k=%d  |Mr|/|Mr0| = %.3e\n", k, nz / beta0);
         if (nz <= rtol * beta0) {
@@ -1433,7 +1442,7 @@ struct Engine {
   std::vector<V3> fg_V, fg_Z;
   V3 fg_r{nullptr, nullptr, nullptr}, fg_w{nullptr, nullptr, nullptr}, fg_b{nullptr, nullptr, nullptr};
   V3 alloc3() { return V3{dalloc(NQ), dalloc(NPv), dalloc(NLv)}; }
-  double dot3(const V3& a, const V3& b) { return dot(NQ, a.u, b.u, KC) + dot(NPv, a.p, b.p, KC) + dot(NLv, a.l, b.l, KL); }
+  double dot3(const V3& a, const V3& b) { return dot(NQ, a.u, b.u, KQ) + dot(NPv, a.p, b.p, KC) + dot(NLv, a.l, b.l, KL); }
   void axpby3(double a, const V3& x, double b, V3& y) { axpby(NQ, a, x.u, b, y.u); axpby(NPv, a, x.p, b, y.p); axpby(NLv, a, x.l, b, y.l); }
   void copy3(V3& d, const V3& s_) { copy(d.u, s_.u, NQ); copy(d.p, s_.p, NPv); copy(d.l, s_.l, NLv); }
   void mono_apply(const V3& x, const double* qstar, double gamma, V3& out) {
@@ -2035,7 +2044,7 @@ int hdg_node_coordinates(hdg_handle* h, double* xq, double* xp) {
 }
 int hdg_l2_norms(hdg_handle* h, const double* Q, const double* p, double* norm_Q, double* norm_p) {
   HDG_API_BEGIN(h)
-  if (Q && norm_Q) { E.put_Q(Q, E.wQ1); *norm_Q = std::sqrt(E.dot(E.NQ, E.wQ1, E.wQ1, hdg::Engine::KC)); }
+  if (Q && norm_Q) { E.put_Q(Q, E.wQ1); *norm_Q = std::sqrt(E.dot(E.NQ, E.wQ1, E.wQ1, hdg::Engine::KQ)); }
   if (p && norm_p) { E.put_P(p, E.wP1); *norm_p = std::sqrt(E.dot(E.NPv, E.wP1, E.wP1, hdg::Engine::KC)); }
   HDG_API_END(h)
 }

@@ -3,7 +3,12 @@
 // Data layout in HBM (all float64, modal coefficients in PHYSICALLY orthonormal bases):
 //   cell vectors   v[(n * Nc) + c],  c = (s*ny + j)*nx + i   (dof-major, cell fastest;
 //                  consecutive lanes <-> consecutive i  => every global access is coalesced)
-//   velocity       n = d*NU + m  (component d, Dubiner mode m),  pressure n = m
+//   pressure       n = m (Dubiner mode), 8 bytes per lane per access
+//   velocity       v[(m * Nc + c) * 2 + d]  (mode-major, cell fastest, COMPONENT PAIR innermost): one lane reads or
+//                  writes both components of a mode with ONE 16-byte access (buffer_load/store_dwordx4, 1 KiB per
+//                  wave-instruction).  Measured on MI355X: 8-byte-per-lane streams top out at ~4.9-5.1 TB/s (the
+//                  rate of a triad with double accesses), 16-byte ones at ~6.3 TB/s.  Inside a kernel the local
+//                  arrays keep the order n = d*NU + m of the operator tables.
 //   trace vectors  l[((t*NL + m) * G) + j*P + i],  t = 0 (H), 1 (V), 2 (D),  corner-indexed on a
 //                  padded (ny+1) x P grid; entries that are not edges stay exactly zero.
 // One thread owns one cell (or one grid corner = up to three edges); the element shape s is
@@ -134,6 +139,52 @@ __device__ __forceinline__ void store_cell(double* __restrict__ v, long Nc, long
   for (int n = 0; n < N; n++) B.st(plane_bytes(n, Nc), lane_b, x[n]);
 }
 
+// Velocity vectors (component-pair layout, see the header): pair-plane m of cell c at double index (m*Nc + c)*2.
+typedef double hdg_d2 __attribute__((ext_vector_type(2)));
+typedef unsigned int hdg_u32x4 __attribute__((ext_vector_type(4)));
+struct VelBuf {
+  __amdgpu_buffer_rsrc_t r;
+  __device__ __forceinline__ explicit VelBuf(const double* p)
+      : r(__builtin_amdgcn_make_buffer_rsrc((void*)p, 0, 0xFFFFFFFF, 0x00020000)) {}
+  // pair-plane offset in bytes (wave uniform), lane offset in bytes (cell * 16)
+  __device__ __forceinline__ hdg_d2 ld(unsigned plane_b, unsigned lane_b) const {
+    return __builtin_bit_cast(hdg_d2, __builtin_amdgcn_raw_buffer_load_b128(r, lane_b, plane_b, 0));
+  }
+  // Stores put the plane offset into the VECTOR offset (soffset = 0).  Measured on gfx950: a 16-byte buffer store
+  // whose data registers are overwritten by the next VALU instruction can still read the new value (low dwords of
+  // a few lanes: run-to-run differences of 2^-21 relative in k_adv_apply<1>); hipcc pads that hazard with wait
+  // states only for stores WITHOUT a scalar offset register (its model: an SGPR offset makes the store safe).
+  __device__ __forceinline__ void st(unsigned plane_b, unsigned lane_b, hdg_d2 x) const {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(hdg_u32x4, x), r, lane_b + plane_b, 0, 0);
+  }
+};
+__device__ __forceinline__ unsigned pair_bytes(int m, long Nc) { return (unsigned)((unsigned long)m * (unsigned long)Nc * 16ul); }
+// index of local dof n = d*NU + m of cell c (for the few 8-byte accesses that remain)
+template <int NU>
+__device__ __forceinline__ long vix(int n, long Nc, long c) {
+  const int d = n >= NU ? 1 : 0, m = n - d * NU;
+  return (((long)m * Nc + c) << 1) + d;
+}
+// x[m] = x-component, x[NU + m] = y-component of mode m
+template <int NU>
+__device__ __forceinline__ void load_vel(const double* __restrict__ v, long Nc, long c, double (&x)[2 * NU]) {
+  const VelBuf B(v);
+  const unsigned lane_b = (unsigned)c * 16u;
+#pragma unroll
+  for (int m = 0; m < NU; m++) {
+    const hdg_d2 t = B.ld(pair_bytes(m, Nc), lane_b);
+    x[m] = t.x;
+    x[NU + m] = t.y;
+  }
+}
+template <int NU>
+__device__ __forceinline__ void store_vel(double* __restrict__ v, long Nc, long c, const double (&x)[2 * NU]) {
+  const VelBuf B(v);
+  const unsigned lane_b = (unsigned)c * 16u;
+#pragma unroll
+  for (int m = 0; m < NU; m++) B.st(pair_bytes(m, Nc), lane_b, hdg_d2{x[m], x[NU + m]});
+}
+
 // y[r] += sc * sum_c A[r*NC + c] x[c]   (A wave-uniform -> scalar loads)
 template <int NR, int NC>
 __device__ __forceinline__ void mv_acc(const double* __restrict__ A, const double (&x)[NC], double (&y)[NR], double sc) {
@@ -189,7 +240,7 @@ void k_edge_lift(Geo g, DevTables T, const double* __restrict__ in,
   constexpr int NU = Dim<K>::NU, NE = Dim<K>::NE, N2 = 2 * NU;
   HDG_CELL_PROLOGUE
   double y[N2], down[3][NE];
-  load_cell<N2>(in, g.Nc, c, y);
+  load_vel<NU>(in, g.Nc, c, y);
 #pragma unroll
   for (int e = 0; e < 3; e++) {
 #pragma unroll
@@ -198,7 +249,7 @@ void k_edge_lift(Geo g, DevTables T, const double* __restrict__ in,
   }
   if (ADD_BJ == 1) {
     double rr[N2];
-    load_cell<N2>(r, g.Nc, c, rr);
+    load_vel<NU>(r, g.Nc, c, rr);
     mv_acc<N2, N2>(s == 0 ? Dinv0 : Dinv1, rr, y, 1.0);
   }
 #pragma unroll
@@ -209,14 +260,14 @@ void k_edge_lift(Geo g, DevTables T, const double* __restrict__ in,
     long cn;
     if (nbr(s, e, i, j, g, cn)) {
       double xn[N2];
-      load_cell<N2>(in, g.Nc, cn, xn);
+      load_vel<NU>(in, g.Nc, cn, xn);
       mv_acc<NE, N2>(Inb, xn, down[e], 1.0);
 #pragma unroll
       for (int a = 0; a < NE; a++) down[e][a] *= 0.5;
     }
     mv_acc<N2, NE>(Out, down[e], y, 1.0);
   }
-  if (out) store_cell<N2>(out, g.Nc, c, y);
+  if (out) store_vel<NU>(out, g.Nc, c, y);
   if (cell_ss) {
     // squared norm of this cell's part of the result (convergence checks: a 1/N2-sized array instead of the
     // whole vector goes through memory; summed deterministically by the multi-dot kernel)
@@ -233,26 +284,33 @@ void k_edge_lift(Geo g, DevTables T, const double* __restrict__ in,
     // inside, every element became its own branch -> load -> wait -> store block.  Each half issues its loads back
     // to back, then its stores.
     const bool rd = (c1 != 0.0);
-    const CellBuf Bp(chd), Bx(chx);
-    const unsigned lane_b = (unsigned)c * 8u;
+    const VelBuf Bp(chd), Bx(chx);
+    const unsigned lane_b = (unsigned)c * 16u;
+    constexpr int NCH = NU >= 10 ? 2 : 1;  // mode pairs per chunk: two batches of 16-byte loads keep the register peak low
 #pragma unroll
-    for (int half = 0; half < 2; half++) {
-      constexpr int H2 = N2 / 2;
-      double pp[H2], xx[H2];
+    for (int ch = 0; ch < NCH; ch++) {
+      const int m_lo = ch * NU / NCH, m_hi = (ch + 1) * NU / NCH;
+      hdg_d2 pp[NU], xx[NU];
 #pragma unroll
-      for (int n = 0; n < H2; n++) xx[n] = Bx.ld(plane_bytes(half * H2 + n, g.Nc), lane_b);
+      for (int m = 0; m < NU; m++)
+        if (m >= m_lo && m < m_hi) xx[m] = Bx.ld(pair_bytes(m, g.Nc), lane_b);
       if (rd) {
 #pragma unroll
-        for (int n = 0; n < H2; n++) pp[n] = Bp.ld(plane_bytes(half * H2 + n, g.Nc), lane_b);
+        for (int m = 0; m < NU; m++)
+          if (m >= m_lo && m < m_hi) pp[m] = Bp.ld(pair_bytes(m, g.Nc), lane_b);
       } else {
 #pragma unroll
-        for (int n = 0; n < H2; n++) pp[n] = xx[n];
+        for (int m = 0; m < NU; m++)
+          if (m >= m_lo && m < m_hi) pp[m] = xx[m];
       }
 #pragma unroll
-      for (int n = 0; n < H2; n++) {
-        const double xn1 = fma(c1, xx[n] - pp[n], fma(c2, y[half * H2 + n], xx[n]));
-        Bp.st(plane_bytes(half * H2 + n, g.Nc), lane_b, xn1);
-      }
+      for (int m = 0; m < NU; m++)
+        if (m >= m_lo && m < m_hi) {
+          hdg_d2 xn1;
+          xn1.x = fma(c1, xx[m].x - pp[m].x, fma(c2, y[m], xx[m].x));
+          xn1.y = fma(c1, xx[m].y - pp[m].y, fma(c2, y[NU + m], xx[m].y));
+          Bp.st(pair_bytes(m, g.Nc), lane_b, xn1);
+        }
     }
   }
 }
@@ -264,14 +322,17 @@ void k_edge_lift(Geo g, DevTables T, const double* __restrict__ in,
 //   (2) neighbour moments       d_e += N'_e x_nbr(e)     then d *= 1/2 where the neighbour exists
 //   (3) lifting                 y   = x + G d            G: 2NU x packed moments (Lift_e, or (I - Dinv) Lift_e)
 // One wave owns 16 consecutive cells of one shape and row (the N dimension of v_mfma_f64_16x16x4); the
-// coefficient planes in[n*Nc + c] are the B operands (lane l: plane 4ks + l/16, cell c0 + l%16 -- 128-byte
-// segments); the tables are packed on the host in A-operand lane order (Engine::pack_lift_mfma), staged in LDS
+// coefficient planes are the B operands.  The K / M dimension over the 2NU velocity dofs runs in MEMORY order
+// kappa = 2m + d (component pair innermost: lanes l/16 = 0,1 read the two halves of one 16-byte pair, so a
+// wave-instruction covers two 256-byte segments; the host packs the table columns / rows in the same order); the tables are packed on the host in A-operand lane order (Engine::pack_lift_mfma), staged in LDS
 // once per workgroup and read back one tile per MFMA (conflict-free ds_read_b64); d changes from accumulator
 // to operand layout through a 4 KB LDS slab per wave.  Packed moment rows: tile 0 = edges 0 and 1 (rows e*NE+a),
 // tile 1 = edge 2 (rows a).  A workgroup (8 waves sharing one LDS copy of the tables) handles one (row, shape);
 // wave w the tiles w, w+8, ...
 // ------------------------------------------------------------------------------------------
 typedef double hdg_v4d __attribute__((ext_vector_type(4)));
+// double index of velocity dof kappa = 2m + d of cell c (memory order of the component-pair layout)
+__device__ __forceinline__ long kix(int kappa, long Nc, long c) { return (((long)(kappa >> 1) * Nc + c) << 1) + (kappa & 1); }
 template <int K>
 struct LiftMfma {
   static constexpr int NU = Dim<K>::NU, NE = Dim<K>::NE, N2 = 2 * NU;
@@ -322,7 +383,7 @@ __global__ __launch_bounds__(64 * HDG_LIFT_MFMA_WAVES) void k_edge_lift_mfma(Geo
 #pragma unroll
     for (int ks = 0; ks < KS; ks++) {
       const int n = 4 * ks + lk;
-      const double b = (n < N2) ? in[(long)n * g.Nc + c] : 0.0;
+      const double b = (n < N2) ? in[kix(n, g.Nc, c)] : 0.0;
       D0 = __builtin_amdgcn_mfma_f64_16x16x4f64(tW[(0 * KS + ks) * 64 + l], b, D0, 0, 0, 0);
       D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(tW[(1 * KS + ks) * 64 + l], b, D1, 0, 0, 0);
     }
@@ -331,9 +392,9 @@ __global__ __launch_bounds__(64 * HDG_LIFT_MFMA_WAVES) void k_edge_lift_mfma(Geo
     for (int ks = 0; ks < KS; ks++) {
       const int n = 4 * ks + lk;
       const bool nv = n < N2;
-      const double b0 = (nv && has0) ? in[(long)n * g.Nc + cn0] : 0.0;
-      const double b1 = nv ? in[(long)n * g.Nc + cn1] : 0.0;
-      const double b2 = (nv && has2) ? in[(long)n * g.Nc + cn2] : 0.0;
+      const double b0 = (nv && has0) ? in[kix(n, g.Nc, cn0)] : 0.0;
+      const double b1 = nv ? in[kix(n, g.Nc, cn1)] : 0.0;
+      const double b2 = (nv && has2) ? in[kix(n, g.Nc, cn2)] : 0.0;
       D0 = __builtin_amdgcn_mfma_f64_16x16x4f64(tN[(0 * KS + ks) * 64 + l], b0, D0, 0, 0, 0);
       D0 = __builtin_amdgcn_mfma_f64_16x16x4f64(tN[(1 * KS + ks) * 64 + l], b1, D0, 0, 0, 0);
       D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(tN[(2 * KS + ks) * 64 + l], b2, D1, 0, 0, 0);
@@ -361,14 +422,14 @@ __global__ __launch_bounds__(64 * HDG_LIFT_MFMA_WAVES) void k_edge_lift_mfma(Geo
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const int n = 16 * mt + lk + 4 * r;
-        Y[r] = (n < N2) ? in[(long)n * g.Nc + c] : 0.0;
+        Y[r] = (n < N2) ? in[kix(n, g.Nc, c)] : 0.0;
       }
 #pragma unroll
       for (int kd = 0; kd < KD; kd++) Y = __builtin_amdgcn_mfma_f64_16x16x4f64(tG[(mt * KD + kd) * 64 + l], bd[kd], Y, 0, 0, 0);
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const int n = 16 * mt + lk + 4 * r;
-        if (n < N2 && col) out[(long)n * g.Nc + c] = Y[r];
+        if (n < N2 && col) out[kix(n, g.Nc, c)] = Y[r];
       }
     }
   }
@@ -393,8 +454,8 @@ void k_adv_apply(Geo g, DevTables T, const double* __restrict__ xin,
   constexpr int NU = Dim<K>::NU, N2 = 2 * NU;
   HDG_CELL_PROLOGUE
   double x[N2], qs[N2], F[N2];
-  load_cell<N2>(xin, g.Nc, c, x);
-  load_cell<N2>(qstar, g.Nc, c, qs);
+  load_vel<NU>(xin, g.Nc, c, x);
+  load_vel<NU>(qstar, g.Nc, c, qs);
 #pragma unroll
   for (int n = 0; n < N2; n++) F[n] = 0.0;
   // ---- cell term
@@ -433,7 +494,7 @@ void k_adv_apply(Geo g, DevTables T, const double* __restrict__ xin,
     long cn;
     const bool has = nbr(s, e, i, j, g, cn);
     double xn[N2];
-    if (has) load_cell<N2>(xin, g.Nc, cn, xn);
+    if (has) load_vel<NU>(xin, g.Nc, cn, xn);
     else {
 #pragma unroll
       for (int n = 0; n < N2; n++) xn[n] = 0.0;
@@ -471,14 +532,14 @@ void k_adv_apply(Geo g, DevTables T, const double* __restrict__ xin,
   }
   if (bsub) {
     double bb[N2];
-    load_cell<N2>(bsub, g.Nc, c, bb);
+    load_vel<NU>(bsub, g.Nc, c, bb);
 #pragma unroll
     for (int n = 0; n < N2; n++) F[n] = bb[n] - fma(-gamma, F[n], x[n]);
   } else {
 #pragma unroll
     for (int n = 0; n < N2; n++) F[n] = fma(-gamma, F[n], x[n]);
   }
-  store_cell<N2>(out, g.Nc, c, F);
+  store_vel<NU>(out, g.Nc, c, F);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -506,10 +567,12 @@ __global__ __launch_bounds__(128) void k_adv_apply2(Geo g, DevTables T, const do
   const int j = xcd_ * g.rows_xcd + jj_;
   if (jj_ >= g.rows_xcd || j >= g.ny || i >= g.nx) return;  // both lanes of a pair leave together
   const long c = ((long)s * (g.ny + 2) + (j + 1)) * g.nx + i;
-  const long cbase = (long)a * NU * g.Nc + c;
+  // lane parity = component = the slot inside a mode's 16-byte pair: a lane pair reads one pair per mode
+  const long cbase = (c << 1) + a;
+  const long pstride = g.Nc << 1;  // doubles between consecutive modes
   double x[NU], qs[NU], F[NU];
 #pragma unroll
-  for (int m = 0; m < NU; m++) { x[m] = xin[cbase + (long)m * g.Nc]; qs[m] = qstar[cbase + (long)m * g.Nc]; F[m] = 0.0; }
+  for (int m = 0; m < NU; m++) { x[m] = xin[cbase + (long)m * pstride]; qs[m] = qstar[cbase + (long)m * pstride]; F[m] = 0.0; }
   // ---- cell term:  F_a[m] -= w Phi[q,m] (Q*.grad) x_a
   {
     const double* __restrict__ Phi = T.cPhi[s];
@@ -540,7 +603,7 @@ __global__ __launch_bounds__(128) void k_adv_apply2(Geo g, DevTables T, const do
     double xn[NU];
     if (has) {
 #pragma unroll
-      for (int m = 0; m < NU; m++) xn[m] = xin[((long)a * NU + m) * g.Nc + cn];
+      for (int m = 0; m < NU; m++) xn[m] = xin[(((long)m * g.Nc + cn) << 1) + a];
     } else {
 #pragma unroll
       for (int m = 0; m < NU; m++) xn[m] = 0.0;
@@ -573,10 +636,10 @@ __global__ __launch_bounds__(128) void k_adv_apply2(Geo g, DevTables T, const do
   }
   if (bsub) {
 #pragma unroll
-    for (int m = 0; m < NU; m++) out[cbase + (long)m * g.Nc] = bsub[cbase + (long)m * g.Nc] - fma(-gamma, F[m], x[m]);
+    for (int m = 0; m < NU; m++) out[cbase + (long)m * pstride] = bsub[cbase + (long)m * pstride] - fma(-gamma, F[m], x[m]);
   } else {
 #pragma unroll
-    for (int m = 0; m < NU; m++) out[cbase + (long)m * g.Nc] = fma(-gamma, F[m], x[m]);
+    for (int m = 0; m < NU; m++) out[cbase + (long)m * pstride] = fma(-gamma, F[m], x[m]);
   }
 }
 
@@ -672,10 +735,11 @@ __global__ __launch_bounds__(512) void k_adv_mfma(Geo g, DevTables T, const doub
     for (int ks = 0; ks < KSU; ks++) {
       const int m = 4 * ks + lk;
       const bool mv = m < NU;
-      bq0[ks] = mv ? qstar[(long)m * g.Nc + c] : 0.0;
-      bq1[ks] = mv ? qstar[(long)(NU + m) * g.Nc + c] : 0.0;
-      bx0[ks] = mv ? xin[(long)m * g.Nc + c] : 0.0;
-      bx1[ks] = mv ? xin[(long)(NU + m) * g.Nc + c] : 0.0;
+      // one 16-byte access per mode: both components (4 pair-planes x 16 cells = four 256-byte segments per instruction)
+      const hdg_d2 tq = mv ? *reinterpret_cast<const hdg_d2*>(qstar + (((long)m * g.Nc + c) << 1)) : hdg_d2{0.0, 0.0};
+      const hdg_d2 tx = mv ? *reinterpret_cast<const hdg_d2*>(xin + (((long)m * g.Nc + c) << 1)) : hdg_d2{0.0, 0.0};
+      bq0[ks] = tq.x; bq1[ks] = tq.y;
+      bx0[ks] = tx.x; bx1[ks] = tx.y;
     }
     hdg_v4d F[2][MTU];
 #pragma unroll
@@ -732,9 +796,11 @@ __global__ __launch_bounds__(512) void k_adv_mfma(Geo g, DevTables T, const doub
     for (int ks = 0; ks < KSU; ks++) {
       const int m = 4 * ks + lk;
       const bool mv = m < NU;
-      const double n00 = (mv && has0) ? xin[(long)m * g.Nc + cn0] : 0.0, n01 = (mv && has0) ? xin[(long)(NU + m) * g.Nc + cn0] : 0.0;
-      const double n10 = mv ? xin[(long)m * g.Nc + cn1] : 0.0, n11 = mv ? xin[(long)(NU + m) * g.Nc + cn1] : 0.0;
-      const double n20 = (mv && has2) ? xin[(long)m * g.Nc + cn2] : 0.0, n21 = (mv && has2) ? xin[(long)(NU + m) * g.Nc + cn2] : 0.0;
+      const hdg_d2 zz = {0.0, 0.0};
+      const hdg_d2 t0 = (mv && has0) ? *reinterpret_cast<const hdg_d2*>(xin + (((long)m * g.Nc + cn0) << 1)) : zz;
+      const hdg_d2 t1 = mv ? *reinterpret_cast<const hdg_d2*>(xin + (((long)m * g.Nc + cn1) << 1)) : zz;
+      const hdg_d2 t2 = (mv && has2) ? *reinterpret_cast<const hdg_d2*>(xin + (((long)m * g.Nc + cn2) << 1)) : zz;
+      const double n00 = t0.x, n01 = t0.y, n10 = t1.x, n11 = t1.y, n20 = t2.x, n21 = t2.y;
       const double e0 = tEN[(0 * KSU + ks) * 64 + l], e1 = tEN[(1 * KSU + ks) * 64 + l], e2 = tEN[(2 * KSU + ks) * 64 + l];
       NBX[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(e0, n00, NBX[0], 0, 0, 0);
       NBY[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(e0, n01, NBY[0], 0, 0, 0);
@@ -772,20 +838,26 @@ __global__ __launch_bounds__(512) void k_adv_mfma(Geo g, DevTables T, const doub
       }
     }
     __builtin_amdgcn_wave_barrier();
-    // ---- result
+    // ---- result: both components of a mode in one 16-byte access
 #pragma unroll
-    for (int a = 0; a < 2; a++)
+    for (int mu = 0; mu < MTU; mu++)
 #pragma unroll
-      for (int mu = 0; mu < MTU; mu++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const int m = 16 * mu + lk + 4 * r;
-          if (m < NU && col) {
-            const long idx = (long)(a * NU + m) * g.Nc + c;
-            const double v = fma(-gamma, F[a][mu][r], xin[idx]);
-            out[idx] = bsub ? bsub[idx] - v : v;
+      for (int r = 0; r < 4; r++) {
+        const int m = 16 * mu + lk + 4 * r;
+        if (m < NU && col) {
+          const long idx = ((long)m * g.Nc + c) << 1;
+          const hdg_d2 xo = *reinterpret_cast<const hdg_d2*>(xin + idx);
+          hdg_d2 v;
+          v.x = fma(-gamma, F[0][mu][r], xo.x);
+          v.y = fma(-gamma, F[1][mu][r], xo.y);
+          if (bsub) {
+            const hdg_d2 bb = *reinterpret_cast<const hdg_d2*>(bsub + idx);
+            v.x = bb.x - v.x;
+            v.y = bb.y - v.y;
           }
+          *reinterpret_cast<hdg_d2*>(out + idx) = v;
         }
+      }
   }
 }
 // ------------------------------------------------------------------------------------------
@@ -795,12 +867,12 @@ template <int K>
 __global__ __launch_bounds__(128) void k_blockdiag(Geo g, const double* __restrict__ Dinv0,
                                                     const double* __restrict__ Dinv1, const double* __restrict__ r,
                                                     const double* __restrict__ zin, double cz, double* __restrict__ out) {
-  constexpr int N2 = 2 * Dim<K>::NU;
+  constexpr int NU = Dim<K>::NU, N2 = 2 * NU;
   HDG_CELL_PROLOGUE
   double x[N2], y[N2];
-  load_cell<N2>(r, g.Nc, c, x);
+  load_vel<NU>(r, g.Nc, c, x);
   if (zin) {
-    load_cell<N2>(zin, g.Nc, c, y);
+    load_vel<NU>(zin, g.Nc, c, y);
 #pragma unroll
     for (int n = 0; n < N2; n++) y[n] *= cz;
   } else {
@@ -808,7 +880,7 @@ __global__ __launch_bounds__(128) void k_blockdiag(Geo g, const double* __restri
     for (int n = 0; n < N2; n++) y[n] = 0.0;
   }
   mv_acc<N2, N2>(s == 0 ? Dinv0 : Dinv1, x, y, 1.0);
-  store_cell<N2>(out, g.Nc, c, y);
+  store_vel<NU>(out, g.Nc, c, y);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -822,10 +894,15 @@ __global__ __launch_bounds__(128) void k_pgrad(Geo g, DevTables T, const double*
   constexpr int NU = Dim<K>::NU, NP = Dim<K>::NP, NL = Dim<K>::NL, N2 = 2 * NU;
   HDG_CELL_PROLOGUE
   double y[N2], pp[NP], acc[N2];
+  {
+    double ta[N2], tb[N2];
+    if (a) load_vel<NU>(a, g.Nc, c, ta);
+    if (b) load_vel<NU>(b, g.Nc, c, tb);
 #pragma unroll
-  for (int n = 0; n < N2; n++) {
-    y[n] = (a ? ca * a[(long)n * g.Nc + c] : 0.0) + (b ? cb * b[(long)n * g.Nc + c] : 0.0);
-    acc[n] = 0.0;
+    for (int n = 0; n < N2; n++) {
+      y[n] = (a ? ca * ta[n] : 0.0) + (b ? cb * tb[n] : 0.0);
+      acc[n] = 0.0;
+    }
   }
   load_cell<NP>(p, g.Nc, c, pp);
   const double* __restrict__ Bm = T.B[s];
@@ -854,7 +931,8 @@ __global__ __launch_bounds__(128) void k_pgrad(Geo g, DevTables T, const double*
     }
   }
 #pragma unroll
-  for (int n = 0; n < N2; n++) out[(long)n * g.Nc + c] = fma(gamma, acc[n], y[n]);
+  for (int n = 0; n < N2; n++) y[n] = fma(gamma, acc[n], y[n]);
+  store_vel<NU>(out, g.Nc, c, y);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -867,7 +945,7 @@ __global__ __launch_bounds__(128) void k_weak_div(Geo g, DevTables T, const doub
   constexpr int NU = Dim<K>::NU, NP = Dim<K>::NP, NL = Dim<K>::NL, N2 = 2 * NU;
   HDG_CELL_PROLOGUE
   double x[N2], y[NP];
-  load_cell<N2>(q, g.Nc, c, x);
+  load_vel<NU>(q, g.Nc, c, x);
 #pragma unroll
   for (int r = 0; r < NP; r++) y[r] = 0.0;
   if (BROKEN) {
@@ -879,7 +957,7 @@ __global__ __launch_bounds__(128) void k_weak_div(Geo g, DevTables T, const doub
       long cn;
       if (nbr(s, e, i, j, g, cn)) {
         double xn[N2], tr[NL];
-        load_cell<N2>(q, g.Nc, cn, xn);
+        load_vel<NU>(q, g.Nc, cn, xn);
 #pragma unroll
         for (int m = 0; m < NL; m++) tr[m] = 0.0;
         mv_acc_ld<NL, N2>(T.N[s][e], N2, x, tr, 0.5);
@@ -1098,7 +1176,7 @@ __device__ __forceinline__ void y_rows(const double* __restrict__ Y, int erow, c
   constexpr int NU = Dim<K>::NU, NP = Dim<K>::NP, NL = Dim<K>::NL, NX = Dim<K>::NX, N2 = 2 * NU;
   if (HASW) {
     double x[N2];
-    load_cell<N2>(rw, Nc, c, x);
+    load_vel<NU>(rw, Nc, c, x);
     mv_acc_ld<NL, N2>(Y + (long)erow * NL * NX, NX, x, acc, 1.0);
   }
   if (HASP) {
@@ -1148,7 +1226,7 @@ __global__ __launch_bounds__(128) void k_backsub(Geo g, DevTables T, const doubl
   const double* __restrict__ Ai = T.Ainv[s];
   if (HASW) {
     double x[N2];
-    load_cell<N2>(rw, g.Nc, c, x);
+    load_vel<NU>(rw, g.Nc, c, x);
     mv_acc_ld<NX, N2>(Ai, NX, x, y, 1.0);
   }
   if (HASP) {
@@ -1164,8 +1242,11 @@ __global__ __launch_bounds__(128) void k_backsub(Geo g, DevTables T, const doubl
     load_tr<NL>(lam, g, t, off, l + e * NL);
   }
   mv_acc_ld<NX, NT>(T.W[s], NT, l, y, -1.0);
+  {
+    const VelBuf Bu(u);
 #pragma unroll
-  for (int n = 0; n < N2; n++) u[(long)n * g.Nc + c] = y[n];
+    for (int m = 0; m < NU; m++) Bu.st(pair_bytes(m, g.Nc), (unsigned)c * 16u, hdg_d2{y[m], y[NU + m]});
+  }
 #pragma unroll
   for (int n = 0; n < NP; n++) phi[(long)n * g.Nc + c] = y[N2 + n];
 }
@@ -1178,7 +1259,7 @@ __device__ __forceinline__ void trace_side(const DevTables& T, int s, int e, con
                                            double* acc) {
   constexpr int NU = Dim<K>::NU, NP = Dim<K>::NP, NL = Dim<K>::NL, N2 = 2 * NU;
   double x[N2], pp[NP];
-  load_cell<N2>(Q, Nc, c, x);
+  load_vel<NU>(Q, Nc, c, x);
   load_cell<NP>(p, Nc, c, pp);
   mv_acc_ld<NL, N2>(T.N[s][e], N2, x, acc, wq * T.sig[s][e]);
   mv_acc_ld<NL, NP>(T.Pt[s][e], NP, pp, acc, wp);
@@ -1223,8 +1304,8 @@ __global__ __launch_bounds__(128) void k_precon_rhs(Geo g, DevTables T, const do
   constexpr int NU = Dim<K>::NU, NP = Dim<K>::NP, NL = Dim<K>::NL, N2 = 2 * NU;
   HDG_CELL_PROLOGUE
   double x[N2], b[N2], y[NP];
-  load_cell<N2>(Q, g.Nc, c, x);
-  load_cell<N2>(bnew, g.Nc, c, b);
+  load_vel<NU>(Q, g.Nc, c, x);
+  load_vel<NU>(bnew, g.Nc, c, b);
 #pragma unroll
   for (int n = 0; n < N2; n++) b[n] *= bscale;
 #pragma unroll
@@ -1257,8 +1338,8 @@ __global__ __launch_bounds__(128) void k_precon_rhs(Geo g, DevTables T, const do
     const double nx_ = T.enx[e], ny_ = T.eny[e], sg = T.sig[s][e];
     if (has) {
       double xn[N2], bn[N2];
-      load_cell<N2>(Q, g.Nc, cn, xn);
-      load_cell<N2>(bnew, g.Nc, cn, bn);
+      load_vel<NU>(Q, g.Nc, cn, xn);
+      load_vel<NU>(bnew, g.Nc, cn, bn);
       const double* __restrict__ Po = T.ePhi[s][e];
       const double* __restrict__ Gxo = T.eGx[s][e];
       const double* __restrict__ Gyo = T.eGy[s][e];
@@ -1328,7 +1409,7 @@ __global__ __launch_bounds__(128) void k_gamma_psi(Geo g, DevTables T, const dou
   for (int r = 0; r < NP; r++) y[r] = 0.0;
   if (u) {
     double x[N2];
-    load_cell<N2>(u, g.Nc, c, x);
+    load_vel<NU>(u, g.Nc, c, x);
     mv_acc<NP, N2>(T.B[s], x, y, 1.0);
   }
   if (phi || lam) {
@@ -1365,7 +1446,7 @@ __device__ __forceinline__ void gamma_mu_side(const DevTables& T, int s, int e, 
   constexpr int NU = Dim<K>::NU, NP = Dim<K>::NP, NL = Dim<K>::NL, N2 = 2 * NU;
   if (u) {
     double x[N2];
-    load_cell<N2>(u, Nc, c, x);
+    load_vel<NU>(u, Nc, c, x);
     mv_acc_ld<NL, N2>(T.N[s][e], N2, x, acc, T.sig[s][e]);
   }
   if (phi) {
@@ -1422,7 +1503,7 @@ __global__ void k_q_nodal_to_modal(Geo g, DevTables T, const double* __restrict_
     for (int n = 0; n < NU; n++) { v[n] = nodal[(cref * NU + n) * 2 + d]; m[n] = 0.0; }
     mv_acc<NU, NU>(T.Vuinv, v, m, 1.0);
 #pragma unroll
-    for (int n = 0; n < NU; n++) modal[((long)d * NU + n) * g.Nc + c] = m[n];
+    for (int n = 0; n < NU; n++) modal[(((long)n * g.Nc + c) << 1) + d] = m[n];
   }
 }
 template <int K>
@@ -1434,7 +1515,7 @@ __global__ void k_q_modal_to_nodal(Geo g, DevTables T, const double* __restrict_
   for (int d = 0; d < 2; d++) {
     double v[NU], m[NU];
 #pragma unroll
-    for (int n = 0; n < NU; n++) { m[n] = modal[((long)d * NU + n) * g.Nc + c]; v[n] = 0.0; }
+    for (int n = 0; n < NU; n++) { m[n] = modal[(((long)n * g.Nc + c) << 1) + d]; v[n] = 0.0; }
     mv_acc<NU, NU>(T.Vu, m, v, 1.0);
 #pragma unroll
     for (int n = 0; n < NU; n++) nodal[(cref * NU + n) * 2 + d] = v[n];
@@ -1497,39 +1578,74 @@ __global__ void k_l_convert(Geo g, DevTables T, double* __restrict__ nodal, doub
 }
 
 // ------------------------------------------------------------------------------------------
-// vector kernels (grid-stride, 2 doubles per lane per access)
+// vector kernels: grid-stride over PAIRS of doubles, one 16-byte access per lane (global_load/store_dwordx4;
+// 8-byte-per-lane streams stop at ~4.9 TB/s on MI355X, 16-byte ones reach ~6.3 TB/s).  Every vector is a
+// hipMalloc'ed array (256-byte aligned); an odd length leaves one tail element to thread 0.
 // ------------------------------------------------------------------------------------------
+#define HDG_VEC_PROLOGUE                                                     \
+  const long tid_ = (long)blockIdx.x * blockDim.x + threadIdx.x;            \
+  const long stride_ = (long)gridDim.x * blockDim.x;                        \
+  const long NP2_ = N >> 1;                                                 \
+  const bool tail_ = (N & 1) && tid_ == 0;                                  \
+  const long it_ = N - 1;                                                   \
+  (void)it_;
+__device__ __forceinline__ const hdg_d2* as2(const double* p) { return reinterpret_cast<const hdg_d2*>(p); }
+__device__ __forceinline__ hdg_d2* as2(double* p) { return reinterpret_cast<hdg_d2*>(p); }
+__device__ __forceinline__ hdg_d2 fma2(double a, hdg_d2 x, hdg_d2 y) { return hdg_d2{fma(a, x.x, y.x), fma(a, x.y, y.y)}; }
+
 struct LinComb {
   const double* v[8];
   double c[8];
   int n;
 };
 __global__ void k_lincomb(long N, LinComb lc, double* __restrict__ out) {
-  const long stride = (long)gridDim.x * blockDim.x;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < N; idx += stride) {
+  HDG_VEC_PROLOGUE
+  for (long i = tid_; i < NP2_; i += stride_) {
+    hdg_d2 acc = {0.0, 0.0};
+    for (int k = 0; k < lc.n; k++) acc = fma2(lc.c[k], as2(lc.v[k])[i], acc);
+    as2(out)[i] = acc;
+  }
+  if (tail_) {
     double acc = 0.0;
-    for (int k = 0; k < lc.n; k++) acc = fma(lc.c[k], lc.v[k][idx], acc);
-    out[idx] = acc;
+    for (int k = 0; k < lc.n; k++) acc = fma(lc.c[k], lc.v[k][it_], acc);
+    out[it_] = acc;
   }
 }
 // conjugate-gradient updates of the trace solver in one pass each:
 //   x += alpha p ; r -= alpha Ap
-__global__ void k_cg_xr(long N, double alpha, const double* __restrict__ p, const double* __restrict__ Ap,
-                        double* __restrict__ x, double* __restrict__ r) {
-  const long stride = (long)gridDim.x * blockDim.x;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < N; idx += stride) {
-    x[idx] = fma(alpha, p[idx], x[idx]);
-    r[idx] = fma(-alpha, Ap[idx], r[idx]);
+__device__ __forceinline__ void cg_xr_body(long N, double alpha, const double* __restrict__ p, const double* __restrict__ Ap,
+                                           double* __restrict__ x, double* __restrict__ r) {
+  HDG_VEC_PROLOGUE
+  for (long i = tid_; i < NP2_; i += stride_) {
+    const hdg_d2 pv = as2(p)[i], av = as2(Ap)[i], xv = as2(x)[i], rv = as2(r)[i];
+    as2(x)[i] = fma2(alpha, pv, xv);
+    as2(r)[i] = fma2(-alpha, av, rv);
+  }
+  if (tail_) {
+    x[it_] = fma(alpha, p[it_], x[it_]);
+    r[it_] = fma(-alpha, Ap[it_], r[it_]);
   }
 }
 //   p = (z - c n) + beta p      (n: null-space vector; z - c n is the projected preconditioned residual)
+__device__ __forceinline__ void cg_p_body(long N, const double* __restrict__ z, const double* __restrict__ nvec, double c, double beta,
+                                          double* __restrict__ p) {
+  HDG_VEC_PROLOGUE
+  for (long i = tid_; i < NP2_; i += stride_) {
+    const hdg_d2 zp = fma2(-c, as2(nvec)[i], as2(z)[i]);
+    as2(p)[i] = (beta == 0.0) ? zp : fma2(beta, as2(p)[i], zp);
+  }
+  if (tail_) {
+    const double zp = fma(-c, nvec[it_], z[it_]);
+    p[it_] = (beta == 0.0) ? zp : fma(beta, p[it_], zp);
+  }
+}
+__global__ void k_cg_xr(long N, double alpha, const double* __restrict__ p, const double* __restrict__ Ap,
+                        double* __restrict__ x, double* __restrict__ r) {
+  cg_xr_body(N, alpha, p, Ap, x, r);
+}
 __global__ void k_cg_p(long N, const double* __restrict__ z, const double* __restrict__ nvec, double c, double beta,
                        double* __restrict__ p) {
-  const long stride = (long)gridDim.x * blockDim.x;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < N; idx += stride) {
-    const double zp = fma(-c, nvec[idx], z[idx]);
-    p[idx] = (beta == 0.0) ? zp : fma(beta, p[idx], zp);
-  }
+  cg_p_body(N, z, nvec, c, beta, p);
 }
 // Device-resident scalars of the trace CG (no host round trip for alpha / beta / projection coefficient):
 //   sc[0] rz, sc[1] alpha, sc[2] beta, sc[3] c, sc[4] (z',z'), sc[5] p.Ap, sc[6] flag (1 breakdown, 2 cancellation),
@@ -1554,27 +1670,20 @@ __global__ void k_cg_beta(const double* __restrict__ res, double* __restrict__ s
 }
 __global__ void k_cg_xr_dev(long N, const double* __restrict__ sc, const double* __restrict__ p, const double* __restrict__ Ap,
                             double* __restrict__ x, double* __restrict__ r) {
-  const double alpha = sc[1];
-  const long stride = (long)gridDim.x * blockDim.x;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < N; idx += stride) {
-    x[idx] = fma(alpha, p[idx], x[idx]);
-    r[idx] = fma(-alpha, Ap[idx], r[idx]);
-  }
+  cg_xr_body(N, sc[1], p, Ap, x, r);
 }
 __global__ void k_cg_p_dev(long N, const double* __restrict__ z, const double* __restrict__ nvec, const double* __restrict__ sc,
                            double* __restrict__ p) {
-  const double c = sc[3], beta = sc[2];
-  const long stride = (long)gridDim.x * blockDim.x;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < N; idx += stride) {
-    const double zp = fma(-c, nvec[idx], z[idx]);
-    p[idx] = (beta == 0.0) ? zp : fma(beta, p[idx], zp);
-  }
+  cg_p_body(N, z, nvec, sc[3], sc[2], p);
 }
 // y = a*x + b*y
 __global__ void k_axpby(long N, double a, const double* __restrict__ x, double b, double* __restrict__ y) {
-  const long stride = (long)gridDim.x * blockDim.x;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < N; idx += stride)
-    y[idx] = (b == 0.0) ? a * x[idx] : fma(a, x[idx], b * y[idx]);
+  HDG_VEC_PROLOGUE
+  for (long i = tid_; i < NP2_; i += stride_) {
+    const hdg_d2 xv = as2(x)[i];
+    as2(y)[i] = (b == 0.0) ? hdg_d2{a * xv.x, a * xv.y} : fma2(a, xv, hdg_d2{b * as2(y)[i].x, b * as2(y)[i].y});
+  }
+  if (tail_) y[it_] = (b == 0.0) ? a * x[it_] : fma(a, x[it_], b * y[it_]);
 }
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -1591,6 +1700,12 @@ __device__ __forceinline__ double wave_sum(double v) {
 struct RowMask {
   int w_, nrows, lo, hi;
 };
+__device__ __forceinline__ double row_factor(const RowMask& mk, long N, long idx) {
+  // 32-bit arithmetic whenever the index fits (always, up to 2^31 entries): 64-bit division is ~4x dearer
+  const int row = (N <= 0x7fffffffL) ? (int)(((unsigned)idx / (unsigned)mk.w_) % (unsigned)mk.nrows)
+                                     : (int)((idx / mk.w_) % mk.nrows);
+  return (row < mk.lo || row > mk.hi) ? 0.0 : 1.0;
+}
 // vector list passed by value (kernel arguments): no host->device pointer upload per call
 template <int MAXV>
 struct VecList {
@@ -1605,49 +1720,52 @@ __global__ __launch_bounds__(HDG_DOT_BLOCK) void k_multidot(long N, const double
   double accx = 0.0;  // cross product (own register: a runtime index into acc[] would demote it to scratch)
 #pragma unroll
   for (int k = 0; k < MAXV; k++) acc[k] = 0.0;
-  const long stride = (long)gridDim.x * blockDim.x;
-  // U independent elements per trip (lean instantiation only): all their loads are issued before the first FMA.
+  // U independent PAIRS per trip (lean instantiation only): all their loads are issued before the first FMA.
   // Masked-out rows and the tail are handled by a 0/1 factor on w instead of a branch (every index read is a
   // valid one: ghost rows exist, the tail is clamped), so the loads of a trip never wait for a predicate.
-  constexpr int U = MAXV <= 4 ? 4 : 1;
-  const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  for (long base = tid; base < N; base += U * stride) {
-    double wv[U], vv[U][MAXV];
+  constexpr int U = MAXV <= 4 ? 2 : 1;
+  HDG_VEC_PROLOGUE
+  const bool same_row = (mk.w_ & 1) == 0;  // even row length: both entries of a pair lie in the same row
+  for (long base = tid_; base < NP2_; base += U * stride_) {
+    hdg_d2 wv[U], vv[U][MAXV];
 #pragma unroll
     for (int u = 0; u < U; u++) {
-      const long idx0 = base + u * stride;
-      const bool inb = idx0 < N;
-      const long idx = inb ? idx0 : tid;
-      double mf = inb ? 1.0 : 0.0;
+      const long i0 = base + u * stride_;
+      const bool inb = i0 < NP2_;
+      const long i = inb ? i0 : tid_;
+      double m0 = inb ? 1.0 : 0.0, m1 = m0;
       if (mk.w_ > 0) {
-        // 32-bit arithmetic whenever the index fits (always, up to 2^31 entries): 64-bit division is ~4x dearer
-        const int row = (N <= 0x7fffffffL) ? (int)(((unsigned)idx / (unsigned)mk.w_) % (unsigned)mk.nrows)
-                                           : (int)((idx / mk.w_) % mk.nrows);
-        if (row < mk.lo || row > mk.hi) mf = 0.0;
+        m0 *= row_factor(mk, N, 2 * i);
+        m1 = same_row ? m0 : m1 * row_factor(mk, N, 2 * i + 1);
       }
-      wv[u] = w[idx] * mf;
+      const hdg_d2 t = as2(w)[i];
+      wv[u] = hdg_d2{t.x * m0, t.y * m1};
 #pragma unroll
-      for (int k = 0; k < MAXV; k++) vv[u][k] = (k < nv) ? V.p[k][idx] : 0.0;
+      for (int k = 0; k < MAXV; k++) vv[u][k] = (k < nv) ? as2(V.p[k])[i] : hdg_d2{0.0, 0.0};
     }
 #pragma unroll
     for (int u = 0; u < U; u++) {
 #pragma unroll
       for (int k = 0; k < MAXV; k++)
-        if (k < nv) acc[k] = fma(wv[u], vv[u][k], acc[k]);
+        if (k < nv) acc[k] = fma(wv[u].y, vv[u][k].y, fma(wv[u].x, vv[u][k].x, acc[k]));
     }
     if (cross) {
 #pragma unroll
       for (int u = 0; u < U; u++) {
-        const long idx0 = base + u * stride;
-        double mf = idx0 < N ? 1.0 : 0.0;
-        if (mk.w_ > 0 && idx0 < N) {
-          const int row = (N <= 0x7fffffffL) ? (int)(((unsigned)idx0 / (unsigned)mk.w_) % (unsigned)mk.nrows)
-                                             : (int)((idx0 / mk.w_) % mk.nrows);
-          if (row < mk.lo || row > mk.hi) mf = 0.0;
+        const long i0 = base + u * stride_;
+        double m0 = i0 < NP2_ ? 1.0 : 0.0, m1 = m0;
+        if (mk.w_ > 0 && i0 < NP2_) {
+          m0 = row_factor(mk, N, 2 * i0);
+          m1 = same_row ? m0 : row_factor(mk, N, 2 * i0 + 1);
         }
-        accx = fma(mf * vv[u][0], vv[u][1], accx);
+        accx = fma(m1 * vv[u][0].y, vv[u][1].y, fma(m0 * vv[u][0].x, vv[u][1].x, accx));
       }
     }
+  }
+  if (tail_) {
+    const double mf = mk.w_ > 0 ? row_factor(mk, N, it_) : 1.0;
+    for (int k = 0; k < nv; k++) acc[k] = fma(w[it_] * mf, V.p[k][it_], acc[k]);
+    if (cross) accx = fma(mf * V.p[0][it_], V.p[1][it_], accx);
   }
   const int nvo = nv + (cross ? 1 : 0);
   const int lane = threadIdx.x & 63, wv_ = threadIdx.x >> 6;
@@ -1686,11 +1804,16 @@ __global__ void k_reduce_parts(int nblocks, int nv, const double* __restrict__ p
 // Chebyshev step on velocity vectors, three-term form:  pn = x + c1 (x - pn) + c2 z   (pn: x_{n-1} -> x_{n+1})
 __global__ void k_cheb_update(long N, double* __restrict__ pn, const double* __restrict__ z, const double* __restrict__ x,
                               double c1, double c2) {
-  const long stride = (long)gridDim.x * blockDim.x;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < N; idx += stride) {
-    const double xv = x[idx];
-    const double pv = (c1 != 0.0) ? pn[idx] : xv;
-    pn[idx] = fma(c1, xv - pv, fma(c2, z[idx], xv));
+  HDG_VEC_PROLOGUE
+  for (long i = tid_; i < NP2_; i += stride_) {
+    const hdg_d2 xv = as2(x)[i], zv = as2(z)[i];
+    const hdg_d2 pv = (c1 != 0.0) ? as2(pn)[i] : xv;
+    as2(pn)[i] = hdg_d2{fma(c1, xv.x - pv.x, fma(c2, zv.x, xv.x)), fma(c1, xv.y - pv.y, fma(c2, zv.y, xv.y))};
+  }
+  if (tail_) {
+    const double xv = x[it_];
+    const double pv = (c1 != 0.0) ? pn[it_] : xv;
+    pn[it_] = fma(c1, xv - pv, fma(c2, z[it_], xv));
   }
 }
 
@@ -1702,25 +1825,35 @@ struct Coefs {
 template <int MAXV>
 __global__ void k_gs_update(long N, const double* __restrict__ w, const double* const* __restrict__ V, Coefs h, int nv,
                             double scale, double* __restrict__ out) {
-  const long stride = (long)gridDim.x * blockDim.x;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < N; idx += stride) {
-    double acc = w[idx];
+  HDG_VEC_PROLOGUE
+  for (long i = tid_; i < NP2_; i += stride_) {
+    hdg_d2 acc = as2(w)[i];
 #pragma unroll
     for (int k = 0; k < MAXV; k++)
-      if (k < nv) acc = fma(-h.c[k], V[k][idx], acc);
-    out[idx] = scale * acc;
+      if (k < nv) acc = fma2(-h.c[k], as2(V[k])[i], acc);
+    as2(out)[i] = hdg_d2{scale * acc.x, scale * acc.y};
+  }
+  if (tail_) {
+    double acc = w[it_];
+    for (int k = 0; k < nv; k++) acc = fma(-h.c[k], V[k][it_], acc);
+    out[it_] = scale * acc;
   }
 }
 // x += sum_k y[k] V[k]
 template <int MAXV>
 __global__ void k_basis_axpy(long N, double* __restrict__ x, const double* const* __restrict__ V, Coefs y, int nv) {
-  const long stride = (long)gridDim.x * blockDim.x;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < N; idx += stride) {
-    double acc = x[idx];
+  HDG_VEC_PROLOGUE
+  for (long i = tid_; i < NP2_; i += stride_) {
+    hdg_d2 acc = as2(x)[i];
 #pragma unroll
     for (int k = 0; k < MAXV; k++)
-      if (k < nv) acc = fma(y.c[k], V[k][idx], acc);
-    x[idx] = acc;
+      if (k < nv) acc = fma2(y.c[k], as2(V[k])[i], acc);
+    as2(x)[i] = acc;
+  }
+  if (tail_) {
+    double acc = x[it_];
+    for (int k = 0; k < nv; k++) acc = fma(y.c[k], V[k][it_], acc);
+    x[it_] = acc;
   }
 }
 
