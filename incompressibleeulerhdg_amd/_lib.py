@@ -11,7 +11,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhdg_mi355x.so")
+# HDG_LIB_PATH: load an alternative build of the SAME library (kernel experiments with -D switches, tools/)
+LIB_PATH = os.environ.get("HDG_LIB_PATH") or os.path.join(_HERE, "libhdg_mi355x.so")
 SRC = os.path.join(_HERE, "csrc", "hdg_engine.hip")
 HEADER = os.path.normpath(os.path.join(_HERE, "..", "include", "hdg_mi355x.h"))
 

@@ -150,7 +150,11 @@ struct Engine {
   dim3 corner_grid() const { return dim3(8 * g.rows_xcdc * g.nbxc, 1, 1); }
   dim3 corner_grid_all() const { return dim3(8 * g_all.rows_xcdc * g_all.nbxc, 1, 1); }
   int bs() const { return g.nx <= 64 ? 64 : 128; }
-  int vec_blocks(long n) const { return (int)std::min<long>((n + 255) / 256, 2048); }
+  // vector kernels: one 16-byte pair per thread (no grid-stride trips: consecutive workgroups walk memory in order;
+  // tools/probes/stream_probe: 3 reads + 1 write 5.1 TB/s with 2048 blocks, 5.85 with one pair per thread)
+  int vec_blocks(long n) const { return (int)std::min<long>((n / 2 + 255) / 256 + 1, 1L << 22); }
+  // streaming cache policy for vectors that exceed the Infinity Cache together with their partners
+  bool big(long n) const { return n * 8L >= (96L << 20); }
 
   // ------------------------------------------------------------------ construction
   Engine(const hdg_config& c, Comm* comm_) : cfg(c), comm(comm_) {
@@ -197,6 +201,7 @@ struct Engine {
     g.nbxc = (g.nx + 1 + bs() - 1) / bs();
     g.rows_xcd = (g.ny + 7) / 8;
     g.rows_xcdc = (g.nyc + 7) / 8;
+    g.dbg_nonbr = std::getenv("HDG_DBG_NONBR") ? 1 : 0;
     g_all = g;
     g_all.nyc = g.ny + 1;
     g_all.rows_xcdc = (g_all.nyc + 7) / 8;
@@ -281,7 +286,7 @@ struct Engine {
     HIPCHECK(hipMalloc(&p, sizeof(double*) * (std::max(m, MAXV) + 2)));
     allocs.push_back(p);
     d_ptrs = (const double**)p;
-    dot_blocks = 2048;
+    dot_blocks = 8192;
     d_part = dalloc((long)dot_blocks * MAXV);
     d_res = dalloc(MAXV);
     HIPCHECK(hipHostMalloc((void**)&h_res, sizeof(double) * MAXV));
@@ -568,7 +573,16 @@ struct Engine {
   }
   void zero(double* x, long n) { HIPCHECK(hipMemsetAsync(x, 0, sizeof(double) * n, stream)); }
   void axpby(long n, double a, const double* x, double b, double* y) {
-    k_axpby<<<vec_blocks(n), 256, 0, stream>>>(n, a, x, b, y);
+    if (big(n)) k_axpby<true><<<vec_blocks(n), 256, 0, stream>>>(n, a, x, b, y);
+    else k_axpby<false><<<vec_blocks(n), 256, 0, stream>>>(n, a, x, b, y);
+  }
+  void cheb_update(double* pn, const double* z, const double* x, double c1, double c2) {
+    if (big(NQ)) k_cheb_update<true><<<vec_blocks(NQ), 256, 0, stream>>>(NQ, pn, z, x, c1, c2);
+    else k_cheb_update<false><<<vec_blocks(NQ), 256, 0, stream>>>(NQ, pn, z, x, c1, c2);
+  }
+  void gs_update(const double* w, const Coefs& h, int nv, double scale, double* out) {
+    if (big(NQ)) k_gs_update<MAXV, true><<<vec_blocks(NQ), 256, 0, stream>>>(NQ, w, d_gmV, h, nv, scale, out);
+    else k_gs_update<MAXV, false><<<vec_blocks(NQ), 256, 0, stream>>>(NQ, w, d_gmV, h, nv, scale, out);
   }
   void lincomb(long n, const std::vector<std::pair<const double*, double>>& terms, double* out) {
     // merge duplicate pointers, drop zeros, chunks of 8
@@ -587,7 +601,8 @@ struct Engine {
       lc.n = 0;
       if (!first) { lc.v[0] = out; lc.c[0] = 1.0; lc.n = 1; }
       while (lc.n < 8 && off < t.size()) { lc.v[lc.n] = t[off].first; lc.c[lc.n] = t[off].second; lc.n++; off++; }
-      k_lincomb<<<vec_blocks(n), 256, 0, stream>>>(n, lc, out);
+      if (big(n)) k_lincomb<true><<<vec_blocks(n), 256, 0, stream>>>(n, lc, out);
+      else k_lincomb<false><<<vec_blocks(n), 256, 0, stream>>>(n, lc, out);
       first = false;
     }
   }
@@ -615,11 +630,13 @@ struct Engine {
         // the common case (CG / Chebyshev norms: 1-3 vectors): lean instantiation, 8 accumulator registers
         VecList<4> vl;
         for (int q = 0; q < 4; q++) vl.p[q] = q < cnt ? V[off + q] : nullptr;
-        k_multidot<4><<<nb, HDG_DOT_BLOCK, 0, stream>>>(n, w, vl, cnt, d_part, mask_for(kind), cross ? 1 : 0);
+        if (big(n)) k_multidot<4, true><<<nb, HDG_DOT_BLOCK, 0, stream>>>(n, w, vl, cnt, d_part, mask_for(kind), cross ? 1 : 0);
+        else k_multidot<4, false><<<nb, HDG_DOT_BLOCK, 0, stream>>>(n, w, vl, cnt, d_part, mask_for(kind), cross ? 1 : 0);
       } else {
         VecList<MAXV> vl;
         for (int q = 0; q < MAXV; q++) vl.p[q] = q < cnt ? V[off + q] : nullptr;
-        k_multidot<MAXV><<<nb, HDG_DOT_BLOCK, 0, stream>>>(n, w, vl, cnt, d_part, mask_for(kind), cross ? 1 : 0);
+        if (big(n)) k_multidot<MAXV, true><<<nb, HDG_DOT_BLOCK, 0, stream>>>(n, w, vl, cnt, d_part, mask_for(kind), cross ? 1 : 0);
+        else k_multidot<MAXV, false><<<nb, HDG_DOT_BLOCK, 0, stream>>>(n, w, vl, cnt, d_part, mask_for(kind), cross ? 1 : 0);
       }
       k_reduce_parts<<<nout, 256, 0, stream>>>(nb, nout, d_part, d_res);
       comm->allreduce_sum(d_res, nout, stream);
@@ -642,7 +659,7 @@ struct Engine {
     int nb = std::min(dot_blocks, vec_blocks(g.Nc));
     VecList<4> vl{};
     vl.p[0] = ones_c;
-    k_multidot<4><<<nb, HDG_DOT_BLOCK, 0, stream>>>(g.Nc, p, vl, 1, d_part, mask_for(KC), 0);
+    k_multidot<4, false><<<nb, HDG_DOT_BLOCK, 0, stream>>>(g.Nc, p, vl, 1, d_part, mask_for(KC), 0);
     k_reduce_parts<<<1, 256, 0, stream>>>(nb, 1, d_part, d_res);
     comm->allreduce_sum(d_res, 1, stream);
     k_shift_p<<<vec_blocks(g.Nc), 256, 0, stream>>>(g.Nc, p, d_res, c0 / vol, c0);
@@ -755,7 +772,7 @@ struct Engine {
     if (cfg.tent_precond == 0) {
       blockdiag(dinv0[didx], dinv1[didx], r, nullptr, 0.0, wQ4);
       if (zout) copy(zout, wQ4, NQ);
-      k_cheb_update<<<vec_blocks(NQ), 256, 0, stream>>>(NQ, d_, wQ4, x_, c1, c2);
+      cheb_update(d_, wQ4, x_, c1, c2);
     } else if (cfg.tent_precond == 1) {
       bdm_T(r, wQ3);
       bdm_plus_bj(wQ3, zout, r, dinv0[didx], dinv1[didx], d_, x_, c1, c2);
@@ -799,7 +816,7 @@ struct Engine {
       if (beta <= rtol * beta0 || beta == 0.0) return its;
       if (!ritz && beta_prev > 0 && beta > 0.5 * beta_prev) mcur = std::min(m, 2 * mcur);
       beta_prev = beta;
-      k_gs_update<MAXV><<<nvb, 256, 0, stream>>>(NQ, w, d_gmV, Coefs(), 0, 1.0 / beta, gm_V[0]);
+      gs_update(w, Coefs(), 0, 1.0 / beta, gm_V[0]);
       std::fill(gv.begin(), gv.end(), 0.0);
       gv[0] = beta;
       int j = 0;
@@ -823,10 +840,10 @@ struct Engine {
         double hn;
         if (hn2 > 1e-6 * ww) {
           hn = std::sqrt(hn2);
-          k_gs_update<MAXV><<<nvb, 256, 0, stream>>>(NQ, w, d_gmV, hc, j + 1, 1.0 / hn, gm_V[j + 1]);
+          gs_update(w, hc, j + 1, 1.0 / hn, gm_V[j + 1]);
         } else {
           // severe cancellation: orthogonalise explicitly and measure the norm (safe path)
-          k_gs_update<MAXV><<<nvb, 256, 0, stream>>>(NQ, w, d_gmV, hc, j + 1, 1.0, gm_V[j + 1]);
+          gs_update(w, hc, j + 1, 1.0, gm_V[j + 1]);
           hn = std::sqrt(dot(NQ, gm_V[j + 1], gm_V[j + 1], KQ));
           if (hn > 0) axpby(NQ, 0.0, w, 1.0 / hn, gm_V[j + 1]);
         }
@@ -864,7 +881,8 @@ struct Engine {
         y[l] = acc / H[(size_t)l * m + l];
       }
       for (int l = 0; l < j; l++) yc.c[l] = y[l];
-      k_basis_axpy<MAXV><<<nvb, 256, 0, stream>>>(NQ, x, d_gmV, yc, j);
+      if (big(NQ)) k_basis_axpy<MAXV, true><<<nvb, 256, 0, stream>>>(NQ, x, d_gmV, yc, j);
+      else k_basis_axpy<MAXV, false><<<nvb, 256, 0, stream>>>(NQ, x, d_gmV, yc, j);
       if (ritz) {
         // Ritz values: eigenvalues of the leading j x j block of the (unrotated) Hessenberg matrix
         std::vector<double> Hs((size_t)j * j);
@@ -1024,7 +1042,7 @@ struct Engine {
       tent_precond_cheb(didx, t, nullptr, oth, cur, 0.0, 1.0 / theta);
     } else {
       // z = M(b - A x) of the unchanged iterate is already in wQ1 (= z) from the norm evaluation above
-      k_cheb_update<<<nvb, 256, 0, stream>>>(NQ, oth, z, cur, 0.0, 1.0 / theta);
+      cheb_update(oth, z, cur, 0.0, 1.0 / theta);
     }
     std::swap(cur, oth);
     const int ch_head = its;  // iterations of the opening GMRES cycle (0 without an estimate)

@@ -43,6 +43,7 @@ struct Geo {
   int nbxc;      // blocks per row of corners
   int rows_xcd;  // cell rows per XCD band      = ceil(ny / 8)
   int rows_xcdc; // corner rows per XCD band    = ceil((ny+1) / 8)
+  int dbg_nonbr; // experiment switch (HDG_DBG_NONBR, timing only): every edge is treated as a boundary edge
 };
 
 template <int K>
@@ -79,6 +80,7 @@ struct DevTables {
 __device__ __forceinline__ bool nbr(int s, int e, int i, int j, const Geo& g, long& cn) {
   int in, jn;
   bool ok;
+  if (g.dbg_nonbr) { cn = 0; return false; }
   if (s == 0) {
     if (e == 0) { in = i; jn = j - 1; ok = (g.joff + j) > 0; }
     else if (e == 1) { in = i; jn = j; ok = true; }
@@ -142,6 +144,19 @@ __device__ __forceinline__ void store_cell(double* __restrict__ v, long Nc, long
 // Velocity vectors (component-pair layout, see the header): pair-plane m of cell c at double index (m*Nc + c)*2.
 typedef double hdg_d2 __attribute__((ext_vector_type(2)));
 typedef unsigned int hdg_u32x4 __attribute__((ext_vector_type(4)));
+#ifndef HDG_NT_AUX
+#define HDG_NT_AUX 2  // cache-policy bits of the buffer instructions on gfx94x/gfx950: bit 1 = nt
+#endif
+// cache-policy experiment switches.  k_adv_apply: bit 0 Q* loads, bit 1 b loads, bit 2 result
+// stores non-temporal; k_edge_lift Chebyshev epilogue: bit 0 x_n loads, bit 1 x_{n-1} loads, bit 2 x_{n+1} stores
+// Measured at C3 (micro-benchmark / whole step): k_adv_apply 313 -> 293 us with 7, k_edge_lift + Chebyshev 284 -> 243 us
+// with 7; 147-149 -> 142 ms per step with both.
+#ifndef HDG_ADV_NT
+#define HDG_ADV_NT 7
+#endif
+#ifndef HDG_LIFT_NT
+#define HDG_LIFT_NT 7
+#endif
 struct VelBuf {
   __amdgpu_buffer_rsrc_t r;
   __device__ __forceinline__ explicit VelBuf(const double* p)
@@ -149,6 +164,13 @@ struct VelBuf {
   // pair-plane offset in bytes (wave uniform), lane offset in bytes (cell * 16)
   __device__ __forceinline__ hdg_d2 ld(unsigned plane_b, unsigned lane_b) const {
     return __builtin_bit_cast(hdg_d2, __builtin_amdgcn_raw_buffer_load_b128(r, lane_b, plane_b, 0));
+  }
+  // streaming (non-temporal) variants for data no other workgroup reads again before it has left the caches
+  __device__ __forceinline__ hdg_d2 ld_nt(unsigned plane_b, unsigned lane_b) const {
+    return __builtin_bit_cast(hdg_d2, __builtin_amdgcn_raw_buffer_load_b128(r, lane_b, plane_b, HDG_NT_AUX));
+  }
+  __device__ __forceinline__ void st_nt(unsigned plane_b, unsigned lane_b, hdg_d2 x) const {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(hdg_u32x4, x), r, lane_b + plane_b, 0, HDG_NT_AUX);
   }
   // Stores put the plane offset into the VECTOR offset (soffset = 0).  Measured on gfx950: a 16-byte buffer store
   // whose data registers are overwritten by the next VALU instruction can still read the new value (low dwords of
@@ -176,6 +198,24 @@ __device__ __forceinline__ void load_vel(const double* __restrict__ v, long Nc, 
     x[m] = t.x;
     x[NU + m] = t.y;
   }
+}
+template <int NU>
+__device__ __forceinline__ void load_vel_nt(const double* __restrict__ v, long Nc, long c, double (&x)[2 * NU]) {
+  const VelBuf B(v);
+  const unsigned lane_b = (unsigned)c * 16u;
+#pragma unroll
+  for (int m = 0; m < NU; m++) {
+    const hdg_d2 t = B.ld_nt(pair_bytes(m, Nc), lane_b);
+    x[m] = t.x;
+    x[NU + m] = t.y;
+  }
+}
+template <int NU>
+__device__ __forceinline__ void store_vel_nt(double* __restrict__ v, long Nc, long c, const double (&x)[2 * NU]) {
+  const VelBuf B(v);
+  const unsigned lane_b = (unsigned)c * 16u;
+#pragma unroll
+  for (int m = 0; m < NU; m++) B.st_nt(pair_bytes(m, Nc), lane_b, hdg_d2{x[m], x[NU + m]});
 }
 template <int NU>
 __device__ __forceinline__ void store_vel(double* __restrict__ v, long Nc, long c, const double (&x)[2 * NU]) {
@@ -293,11 +333,11 @@ void k_edge_lift(Geo g, DevTables T, const double* __restrict__ in,
       hdg_d2 pp[NU], xx[NU];
 #pragma unroll
       for (int m = 0; m < NU; m++)
-        if (m >= m_lo && m < m_hi) xx[m] = Bx.ld(pair_bytes(m, g.Nc), lane_b);
+        if (m >= m_lo && m < m_hi) xx[m] = (HDG_LIFT_NT & 1) ? Bx.ld_nt(pair_bytes(m, g.Nc), lane_b) : Bx.ld(pair_bytes(m, g.Nc), lane_b);
       if (rd) {
 #pragma unroll
         for (int m = 0; m < NU; m++)
-          if (m >= m_lo && m < m_hi) pp[m] = Bp.ld(pair_bytes(m, g.Nc), lane_b);
+          if (m >= m_lo && m < m_hi) pp[m] = (HDG_LIFT_NT & 2) ? Bp.ld_nt(pair_bytes(m, g.Nc), lane_b) : Bp.ld(pair_bytes(m, g.Nc), lane_b);
       } else {
 #pragma unroll
         for (int m = 0; m < NU; m++)
@@ -309,7 +349,7 @@ void k_edge_lift(Geo g, DevTables T, const double* __restrict__ in,
           hdg_d2 xn1;
           xn1.x = fma(c1, xx[m].x - pp[m].x, fma(c2, y[m], xx[m].x));
           xn1.y = fma(c1, xx[m].y - pp[m].y, fma(c2, y[NU + m], xx[m].y));
-          Bp.st(pair_bytes(m, g.Nc), lane_b, xn1);
+          if (HDG_LIFT_NT & 4) Bp.st_nt(pair_bytes(m, g.Nc), lane_b, xn1); else Bp.st(pair_bytes(m, g.Nc), lane_b, xn1);
         }
     }
   }
@@ -455,7 +495,11 @@ void k_adv_apply(Geo g, DevTables T, const double* __restrict__ xin,
   HDG_CELL_PROLOGUE
   double x[N2], qs[N2], F[N2];
   load_vel<NU>(xin, g.Nc, c, x);
+#if HDG_ADV_NT & 1
+  load_vel_nt<NU>(qstar, g.Nc, c, qs);
+#else
   load_vel<NU>(qstar, g.Nc, c, qs);
+#endif
 #pragma unroll
   for (int n = 0; n < N2; n++) F[n] = 0.0;
   // ---- cell term
@@ -532,14 +576,22 @@ void k_adv_apply(Geo g, DevTables T, const double* __restrict__ xin,
   }
   if (bsub) {
     double bb[N2];
+#if HDG_ADV_NT & 2
+    load_vel_nt<NU>(bsub, g.Nc, c, bb);
+#else
     load_vel<NU>(bsub, g.Nc, c, bb);
+#endif
 #pragma unroll
     for (int n = 0; n < N2; n++) F[n] = bb[n] - fma(-gamma, F[n], x[n]);
   } else {
 #pragma unroll
     for (int n = 0; n < N2; n++) F[n] = fma(-gamma, F[n], x[n]);
   }
+#if HDG_ADV_NT & 4
+  store_vel_nt<NU>(out, g.Nc, c, F);
+#else
   store_vel<NU>(out, g.Nc, c, F);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1591,6 +1643,12 @@ __global__ void k_l_convert(Geo g, DevTables T, double* __restrict__ nodal, doub
   (void)it_;
 __device__ __forceinline__ const hdg_d2* as2(const double* p) { return reinterpret_cast<const hdg_d2*>(p); }
 __device__ __forceinline__ hdg_d2* as2(double* p) { return reinterpret_cast<hdg_d2*>(p); }
+// NT = true: streaming (non-temporal) accesses, for vectors that are larger than the caches anyway (velocity vectors at
+// the benchmark sizes); measured with tools/probes/stream_probe: 3 reads + 1 write 5.85 -> 6.13 TB/s
+template <bool NT>
+__device__ __forceinline__ hdg_d2 ldv(const double* p, long i) { return NT ? __builtin_nontemporal_load(as2(p) + i) : as2(p)[i]; }
+template <bool NT>
+__device__ __forceinline__ void stv(double* p, long i, hdg_d2 v) { if (NT) __builtin_nontemporal_store(v, as2(p) + i); else as2(p)[i] = v; }
 __device__ __forceinline__ hdg_d2 fma2(double a, hdg_d2 x, hdg_d2 y) { return hdg_d2{fma(a, x.x, y.x), fma(a, x.y, y.y)}; }
 
 struct LinComb {
@@ -1598,12 +1656,13 @@ struct LinComb {
   double c[8];
   int n;
 };
+template <bool NT>
 __global__ void k_lincomb(long N, LinComb lc, double* __restrict__ out) {
   HDG_VEC_PROLOGUE
   for (long i = tid_; i < NP2_; i += stride_) {
     hdg_d2 acc = {0.0, 0.0};
-    for (int k = 0; k < lc.n; k++) acc = fma2(lc.c[k], as2(lc.v[k])[i], acc);
-    as2(out)[i] = acc;
+    for (int k = 0; k < lc.n; k++) acc = fma2(lc.c[k], ldv<NT>(lc.v[k], i), acc);
+    stv<NT>(out, i, acc);
   }
   if (tail_) {
     double acc = 0.0;
@@ -1677,11 +1736,16 @@ __global__ void k_cg_p_dev(long N, const double* __restrict__ z, const double* _
   cg_p_body(N, z, nvec, sc[3], sc[2], p);
 }
 // y = a*x + b*y
+template <bool NT>
 __global__ void k_axpby(long N, double a, const double* __restrict__ x, double b, double* __restrict__ y) {
   HDG_VEC_PROLOGUE
   for (long i = tid_; i < NP2_; i += stride_) {
-    const hdg_d2 xv = as2(x)[i];
-    as2(y)[i] = (b == 0.0) ? hdg_d2{a * xv.x, a * xv.y} : fma2(a, xv, hdg_d2{b * as2(y)[i].x, b * as2(y)[i].y});
+    const hdg_d2 xv = ldv<NT>(x, i);
+    if (b == 0.0) stv<NT>(y, i, hdg_d2{a * xv.x, a * xv.y});
+    else {
+      const hdg_d2 yv = ldv<NT>(y, i);
+      stv<NT>(y, i, fma2(a, xv, hdg_d2{b * yv.x, b * yv.y}));
+    }
   }
   if (tail_) y[it_] = (b == 0.0) ? a * x[it_] : fma(a, x[it_], b * y[it_]);
 }
@@ -1711,7 +1775,7 @@ template <int MAXV>
 struct VecList {
   const double* p[MAXV];
 };
-template <int MAXV>
+template <int MAXV, bool NT>
 __global__ __launch_bounds__(HDG_DOT_BLOCK) void k_multidot(long N, const double* __restrict__ w,
                                                              const VecList<MAXV> V, int nv,
                                                              double* __restrict__ part, RowMask mk, int cross) {
@@ -1738,10 +1802,10 @@ __global__ __launch_bounds__(HDG_DOT_BLOCK) void k_multidot(long N, const double
         m0 *= row_factor(mk, N, 2 * i);
         m1 = same_row ? m0 : m1 * row_factor(mk, N, 2 * i + 1);
       }
-      const hdg_d2 t = as2(w)[i];
+      const hdg_d2 t = ldv<NT>(w, i);
       wv[u] = hdg_d2{t.x * m0, t.y * m1};
 #pragma unroll
-      for (int k = 0; k < MAXV; k++) vv[u][k] = (k < nv) ? as2(V.p[k])[i] : hdg_d2{0.0, 0.0};
+      for (int k = 0; k < MAXV; k++) vv[u][k] = (k < nv) ? ldv<NT>(V.p[k], i) : hdg_d2{0.0, 0.0};
     }
 #pragma unroll
     for (int u = 0; u < U; u++) {
@@ -1802,13 +1866,14 @@ __global__ void k_reduce_parts(int nblocks, int nv, const double* __restrict__ p
   }
 }
 // Chebyshev step on velocity vectors, three-term form:  pn = x + c1 (x - pn) + c2 z   (pn: x_{n-1} -> x_{n+1})
+template <bool NT>
 __global__ void k_cheb_update(long N, double* __restrict__ pn, const double* __restrict__ z, const double* __restrict__ x,
                               double c1, double c2) {
   HDG_VEC_PROLOGUE
   for (long i = tid_; i < NP2_; i += stride_) {
-    const hdg_d2 xv = as2(x)[i], zv = as2(z)[i];
-    const hdg_d2 pv = (c1 != 0.0) ? as2(pn)[i] : xv;
-    as2(pn)[i] = hdg_d2{fma(c1, xv.x - pv.x, fma(c2, zv.x, xv.x)), fma(c1, xv.y - pv.y, fma(c2, zv.y, xv.y))};
+    const hdg_d2 xv = ldv<NT>(x, i), zv = ldv<NT>(z, i);
+    const hdg_d2 pv = (c1 != 0.0) ? ldv<NT>(pn, i) : xv;
+    stv<NT>(pn, i, hdg_d2{fma(c1, xv.x - pv.x, fma(c2, zv.x, xv.x)), fma(c1, xv.y - pv.y, fma(c2, zv.y, xv.y))});
   }
   if (tail_) {
     const double xv = x[it_];
@@ -1822,16 +1887,16 @@ struct Coefs {
   double c[32];
 };
 // out = scale * (w - sum_k h[k] V[k])     (classical Gram-Schmidt update fused with the normalisation)
-template <int MAXV>
+template <int MAXV, bool NT>
 __global__ void k_gs_update(long N, const double* __restrict__ w, const double* const* __restrict__ V, Coefs h, int nv,
                             double scale, double* __restrict__ out) {
   HDG_VEC_PROLOGUE
   for (long i = tid_; i < NP2_; i += stride_) {
-    hdg_d2 acc = as2(w)[i];
+    hdg_d2 acc = ldv<NT>(w, i);
 #pragma unroll
     for (int k = 0; k < MAXV; k++)
-      if (k < nv) acc = fma2(-h.c[k], as2(V[k])[i], acc);
-    as2(out)[i] = hdg_d2{scale * acc.x, scale * acc.y};
+      if (k < nv) acc = fma2(-h.c[k], ldv<NT>(V[k], i), acc);
+    stv<NT>(out, i, hdg_d2{scale * acc.x, scale * acc.y});
   }
   if (tail_) {
     double acc = w[it_];
@@ -1840,15 +1905,15 @@ __global__ void k_gs_update(long N, const double* __restrict__ w, const double* 
   }
 }
 // x += sum_k y[k] V[k]
-template <int MAXV>
+template <int MAXV, bool NT>
 __global__ void k_basis_axpy(long N, double* __restrict__ x, const double* const* __restrict__ V, Coefs y, int nv) {
   HDG_VEC_PROLOGUE
   for (long i = tid_; i < NP2_; i += stride_) {
-    hdg_d2 acc = as2(x)[i];
+    hdg_d2 acc = ldv<NT>(x, i);
 #pragma unroll
     for (int k = 0; k < MAXV; k++)
-      if (k < nv) acc = fma2(y.c[k], as2(V[k])[i], acc);
-    as2(x)[i] = acc;
+      if (k < nv) acc = fma2(y.c[k], ldv<NT>(V[k], i), acc);
+    stv<NT>(x, i, acc);
   }
   if (tail_) {
     double acc = x[it_];
