@@ -80,7 +80,7 @@ struct DevTables {
 __device__ __forceinline__ bool nbr(int s, int e, int i, int j, const Geo& g, long& cn) {
   int in, jn;
   bool ok;
-  if (g.dbg_nonbr) { cn = 0; return false; }
+  if (g.dbg_nonbr) { cn = 0; return false; }  // cn = 0: a valid cell index
   if (s == 0) {
     if (e == 0) { in = i; jn = j - 1; ok = (g.joff + j) > 0; }
     else if (e == 1) { in = i; jn = j; ok = true; }
@@ -486,6 +486,54 @@ __global__ __launch_bounds__(64 * HDG_LIFT_MFMA_WAVES) void k_edge_lift_mfma(Geo
 #ifndef HDG_ADV_WAVES
 #define HDG_ADV_WAVES 1
 #endif
+// facet terms of one edge: F += sum_q Po[q] * flux(q)   (xn: coefficients of the neighbour across edge e, zero if none)
+template <int K>
+__device__ __forceinline__ void adv_facet(const DevTables& T, int s, int e, bool has, double upwind, const double (&x)[2 * Dim<K>::NU],
+                                          const double (&qs)[2 * Dim<K>::NU], const double (&xn)[2 * Dim<K>::NU],
+                                          double (&F)[2 * Dim<K>::NU]) {
+  constexpr int NU = Dim<K>::NU;
+  const double* __restrict__ Po = T.ePhi[s][e];
+  const double* __restrict__ Pn = T.ePhi[1 - s][e];
+  const double nx_ = T.enx[e], ny_ = T.eny[e], sg = T.sig[s][e];
+  const double pen = T.alpha / T.elen[e];
+  const int nq = T.nqe;
+#pragma unroll 1
+  for (int q = 0; q < nq; q++) {
+    double ox = 0, oy = 0, bx = 0, by = 0, qn = 0;
+#pragma unroll
+    for (int m = 0; m < NU; m++) {
+      const double po = Po[q * NU + m], pn = Pn[q * NU + m];
+      ox = fma(po, x[m], ox);
+      oy = fma(po, x[NU + m], oy);
+      bx = fma(pn, xn[m], bx);
+      by = fma(pn, xn[NU + m], by);
+      qn = fma(po, fma(nx_, qs[m], ny_ * qs[NU + m]), qn);
+    }
+    if (!has) bx = by = 0.0;  // boundary edge: xn holds whatever the clamped address delivered
+    const double w = T.ew[e][q];
+    const double cf = has ? w * (0.5 * sg * qn - upwind * fabs(qn)) : 0.0;
+    const double jx = ox - bx, jy = oy - by;
+    const double jn = (jx * nx_ + jy * ny_) * pen * w;
+    const double vx = cf * jx - jn * nx_;
+    const double vy = cf * jy - jn * ny_;
+#pragma unroll
+    for (int m = 0; m < NU; m++) {
+      const double po = Po[q * NU + m];
+      F[m] = fma(po, vx, F[m]);
+      F[NU + m] = fma(po, vy, F[NU + m]);
+    }
+  }
+}
+// Software-pipelined neighbour loads (PIPE): the kernel sits at 2 waves/SIMD whatever it does (x, Q*, F and one
+// neighbour array are 160 VGPRs), so the ~50 registers below the 256 limit buy a SECOND neighbour buffer: the
+// coefficients of the next edge's neighbour (and finally b) are requested before the arithmetic of the current
+// edge starts, instead of each edge exposing its own memory latency.  The neighbour loads are UNCONDITIONAL (the
+// neighbour index of a boundary edge points into a ghost row or an adjacent cell, always inside the vector; the
+// trace is zeroed instead): with a load inside `if (has)` the compiler must assume the shorter queue on the other
+// path, and its s_waitcnt vmcnt(N) for the own coefficients then also waits for the prefetched ones.
+#ifndef HDG_ADV_PIPE
+#define HDG_ADV_PIPE 1
+#endif
 template <int K>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(HDG_ADV_WAVES)))
 void k_adv_apply(Geo g, DevTables T, const double* __restrict__ xin,
@@ -500,6 +548,13 @@ void k_adv_apply(Geo g, DevTables T, const double* __restrict__ xin,
 #else
   load_vel<NU>(qstar, g.Nc, c, qs);
 #endif
+  long cn0, cn1, cn2;
+  const bool has0 = nbr(s, 0, i, j, g, cn0), has1 = nbr(s, 1, i, j, g, cn1), has2 = nbr(s, 2, i, j, g, cn2);
+  double xa[N2], xb[N2];
+  // K = 2 only (measured at nx = 1024, residual form: 290.5 -> 286.6 us; K = 1 loses a wave per SIMD, 152 instead of 126
+  // VGPRs: 137.7 -> 140.6 us; K >= 3 is at the register cap and runs on the matrix cores by default)
+  constexpr bool PIPE = HDG_ADV_PIPE != 0 && K == 2;
+  if (PIPE) load_vel<NU>(xin, g.Nc, cn0, xa);
 #pragma unroll
   for (int n = 0; n < N2; n++) F[n] = 0.0;
   // ---- cell term
@@ -533,56 +588,37 @@ void k_adv_apply(Geo g, DevTables T, const double* __restrict__ xin,
     }
   }
   // ---- facet terms
-#pragma unroll
-  for (int e = 0; e < 3; e++) {
-    long cn;
-    const bool has = nbr(s, e, i, j, g, cn);
-    double xn[N2];
-    if (has) load_vel<NU>(xin, g.Nc, cn, xn);
-    else {
-#pragma unroll
-      for (int n = 0; n < N2; n++) xn[n] = 0.0;
+  if (PIPE) {
+    load_vel<NU>(xin, g.Nc, cn1, xb);
+    adv_facet<K>(T, s, 0, has0, upwind, x, qs, xa, F);
+    load_vel<NU>(xin, g.Nc, cn2, xa);
+    adv_facet<K>(T, s, 1, has1, upwind, x, qs, xb, F);
+    if (bsub) {
+#if HDG_ADV_NT & 2
+      load_vel_nt<NU>(bsub, g.Nc, c, xb);
+#else
+      load_vel<NU>(bsub, g.Nc, c, xb);
+#endif
     }
-    const double* __restrict__ Po = T.ePhi[s][e];
-    const double* __restrict__ Pn = T.ePhi[1 - s][e];
-    const double nx_ = T.enx[e], ny_ = T.eny[e], sg = T.sig[s][e];
-    const double pen = T.alpha / T.elen[e];
-    const int nq = T.nqe;
-#pragma unroll 1
-    for (int q = 0; q < nq; q++) {
-      double ox = 0, oy = 0, bx = 0, by = 0, qn = 0;
-#pragma unroll
-      for (int m = 0; m < NU; m++) {
-        const double po = Po[q * NU + m], pn = Pn[q * NU + m];
-        ox = fma(po, x[m], ox);
-        oy = fma(po, x[NU + m], oy);
-        bx = fma(pn, xn[m], bx);
-        by = fma(pn, xn[NU + m], by);
-        qn = fma(po, fma(nx_, qs[m], ny_ * qs[NU + m]), qn);
-      }
-      const double w = T.ew[e][q];
-      const double cf = has ? w * (0.5 * sg * qn - upwind * fabs(qn)) : 0.0;
-      const double jx = ox - bx, jy = oy - by;
-      const double jn = (jx * nx_ + jy * ny_) * pen * w;
-      const double vx = cf * jx - jn * nx_;
-      const double vy = cf * jy - jn * ny_;
-#pragma unroll
-      for (int m = 0; m < NU; m++) {
-        const double po = Po[q * NU + m];
-        F[m] = fma(po, vx, F[m]);
-        F[NU + m] = fma(po, vy, F[NU + m]);
-      }
+    adv_facet<K>(T, s, 2, has2, upwind, x, qs, xa, F);
+  } else {
+    load_vel<NU>(xin, g.Nc, cn0, xa);
+    adv_facet<K>(T, s, 0, has0, upwind, x, qs, xa, F);
+    load_vel<NU>(xin, g.Nc, cn1, xa);
+    adv_facet<K>(T, s, 1, has1, upwind, x, qs, xa, F);
+    load_vel<NU>(xin, g.Nc, cn2, xa);
+    adv_facet<K>(T, s, 2, has2, upwind, x, qs, xa, F);
+    if (bsub) {
+#if HDG_ADV_NT & 2
+      load_vel_nt<NU>(bsub, g.Nc, c, xb);
+#else
+      load_vel<NU>(bsub, g.Nc, c, xb);
+#endif
     }
   }
   if (bsub) {
-    double bb[N2];
-#if HDG_ADV_NT & 2
-    load_vel_nt<NU>(bsub, g.Nc, c, bb);
-#else
-    load_vel<NU>(bsub, g.Nc, c, bb);
-#endif
 #pragma unroll
-    for (int n = 0; n < N2; n++) F[n] = bb[n] - fma(-gamma, F[n], x[n]);
+    for (int n = 0; n < N2; n++) F[n] = xb[n] - fma(-gamma, F[n], x[n]);
   } else {
 #pragma unroll
     for (int n = 0; n < N2; n++) F[n] = fma(-gamma, F[n], x[n]);
