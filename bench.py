@@ -308,6 +308,7 @@ def main():
     if args.warmup > 0:
         eng.run_separable(ssp2_scales(args.warmup, dt, kappa))
     eng.iteration_stats(reset=True)
+    eng.timers(reset=True)
     sync_barrier()
     t0 = time.perf_counter()
     eng.run_separable(ssp2_scales(args.steps, dt, kappa, t0=args.warmup * dt))  # synchronous on return
@@ -322,6 +323,9 @@ def main():
             ("tentative", "pressure", "final_pressure", "pressure_reconstruction"), sums, cnt)}
         ntot = eng.n_total
         value = ntot * args.steps / elapsed / 1e6
+        # device-side section timers of the timed steps (labels of the reference's PerformanceLog)
+        timers = {lab: dict(ncall=n, total_ms=tot * 1e3, avg_ms=(tot / n * 1e3 if n else 0.0))
+                  for lab, (n, tot, _) in eng.timers().items() if n}
         roof = roofline_block(eng, args, nx, k, world)
         line = {
             "metric": "million DOF-updates/sec (HDG-IMEX k=2, 1024^2 tri mesh)" if (nx, k) == (1024, 2)
@@ -336,6 +340,7 @@ def main():
                        "parallelism": f"strip partition over {world} rank(s), transport {backend}"
                                       + (" (ranks share GPUs: rehearsal)" if shared_gpu else "")},
             "roofline": roof,
+            "timers": timers,
         }
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(k)

@@ -155,6 +155,15 @@ int hdg_implicit_step(hdg_handle* h, int* its_tentative, int* its_pressure);
  * sums[4] / counts[4] for tentative, pressure, final pressure, pressure reconstruction */
 int hdg_get_iteration_stats(hdg_handle* h, double* sums, long* counts, int reset);
 
+/* Device-side timers with the labels of the reference's PerformanceLog (src/auxilliary/logging.py:11-60, used at
+ * hdg_imex.py:257,274,551,564,601): index 0 timestep, 1 bdm_projection, 2 tentative_velocity_solve, 3 pressure_solve,
+ * 4 unsplit_solve.  Sections are bracketed by events on the engine's stream (no host synchronisation inside a fused
+ * step), so hdg_step / hdg_run_separable report the same per-solve breakdown as the per-solve calls.  For each label
+ * total_ms[i], sumsq_ms[i] (sum of squares, for the standard deviation log_summary prints) and ncalls[i] since the
+ * last reset. */
+#define HDG_N_TIMERS 5
+int hdg_get_timers(hdg_handle* h, double* total_ms, double* sumsq_ms, long* ncalls, int reset);
+
 /* physical coordinates of the DG nodes, boundary numbering: xq (N_c*n_u, 2), xp (N_c*n_p, 2); what
  * `interpolate` evaluates expressions at (hdg_imex.py:520-521,555; model_problems.py:88-103) */
 int hdg_node_coordinates(hdg_handle* h, double* xq, double* xp);

@@ -117,6 +117,7 @@ SIGNATURES = {
     "hdg_run_separable": [_h, C.c_int, _dp],
     "hdg_implicit_step": [_h, _ip, _ip],
     "hdg_get_iteration_stats": [_h, _dp, _lp, C.c_int],
+    "hdg_get_timers": [_h, _dp, _dp, _lp, C.c_int],
     "hdg_node_coordinates": [_h, _dp, _dp],
     "hdg_l2_norms": [_h, _dp, _dp, _dp, _dp],
     "hdg_integrate_pressure": [_h, _dp, _dp],
@@ -334,6 +335,15 @@ class Engine:
         cnt = np.zeros(4, dtype=np.int64)
         self._ck(self.lib.hdg_get_iteration_stats(self.h, _ptr(sums), cnt.ctypes.data_as(_lp), 1 if reset else 0))
         return sums, cnt
+
+    TIMER_LABELS = ("timestep", "bdm_projection", "tentative_velocity_solve", "pressure_solve", "unsplit_solve")
+
+    def timers(self, reset=False):
+        """Device-side section timers (labels of the reference's PerformanceLog): {label: (ncall, total_s, sumsq_s2)}."""
+        tot, sq = np.zeros(5), np.zeros(5)
+        cnt = np.zeros(5, dtype=np.int64)
+        self._ck(self.lib.hdg_get_timers(self.h, _ptr(tot), _ptr(sq), cnt.ctypes.data_as(_lp), 1 if reset else 0))
+        return {lab: (int(c), t * 1e-3, q * 1e-6) for lab, c, t, q in zip(self.TIMER_LABELS, cnt, tot, sq)}
 
     # --- helpers
     def node_coordinates(self):

@@ -17,6 +17,9 @@ class PerformanceLog(ContextDecorator):
     """Context manager and decorator that records elapsed seconds under a label."""
 
     data = defaultdict(list)
+    # aggregated samples (ncall, total, sum of squares) reported by the engine's device-side section timers when a
+    # whole step runs as one fused call (hdg_get_timers): same labels, merged by log_summary
+    aggregates = defaultdict(lambda: [0, 0.0, 0.0])
 
     def __init__(self, label):
         self.label = label
@@ -30,18 +33,31 @@ class PerformanceLog(ContextDecorator):
         return False
 
     @classmethod
+    def add_aggregate(cls, label, ncall, total, sumsq):
+        a = cls.aggregates[label]
+        a[0] += int(ncall)
+        a[1] += float(total)
+        a[2] += float(sumsq)
+
+    @classmethod
     def reset(cls):
         cls.data.clear()
+        cls.aggregates.clear()
 
 
 def log_summary(file=None):
     """Print ncall / total / avg / std per label, sorted by total time."""
-    if not PerformanceLog.data:
+    if not PerformanceLog.data and not PerformanceLog.aggregates:
         return
     rows = []
-    for label, t in PerformanceLog.data.items():
-        t = np.asarray(t)
-        rows.append((label, len(t), t.sum(), t.mean(), t.std()))
+    for label in set(PerformanceLog.data) | set(PerformanceLog.aggregates):
+        t = np.asarray(PerformanceLog.data.get(label, []), dtype=float)
+        an, atot, asq = PerformanceLog.aggregates.get(label, (0, 0.0, 0.0))
+        n, tot, sq = len(t) + an, t.sum() + atot, (t * t).sum() + asq
+        if n == 0:
+            continue
+        avg = tot / n
+        rows.append((label, n, tot, avg, np.sqrt(max(sq / n - avg * avg, 0.0))))
     print(f"{'timer':>32s} : {'ncall':>6s}    {'total':>10s} {'avg':>10s} {'std':>10s}", file=file)
     print(77 * "-", file=file)
     for label, n, tot, avg, std in sorted(rows, key=lambda r: -r[2]):

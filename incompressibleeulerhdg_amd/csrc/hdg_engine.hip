@@ -118,6 +118,49 @@ struct Engine {
   // boundary staging buffers
   double *hQ_dev, *hP_dev, *hL_dev;
 
+  // ------------------------------------------------------------------ section timers (hdg_get_timers)
+  // Sections are bracketed by events on the stream; elapsed times are harvested once the stream has drained
+  // (the end of every API call), so a fused step needs no synchronisation to report its per-solve breakdown.
+  enum { T_STEP = 0, T_BDM = 1, T_TENT = 2, T_PRESS = 3, T_UNSPLIT = 4 };
+  double tm_total[HDG_N_TIMERS] = {0, 0, 0, 0, 0}, tm_sumsq[HDG_N_TIMERS] = {0, 0, 0, 0, 0};
+  long tm_calls[HDG_N_TIMERS] = {0, 0, 0, 0, 0};
+  struct Section { int label; hipEvent_t e0, e1; };
+  std::vector<Section> tm_open;       // recorded, not yet harvested
+  std::vector<hipEvent_t> tm_pool;    // idle events
+  hipEvent_t tm_event() {
+    if (!tm_pool.empty()) { hipEvent_t e = tm_pool.back(); tm_pool.pop_back(); return e; }
+    hipEvent_t e;
+    HIPCHECK(hipEventCreate(&e));
+    return e;
+  }
+  struct Timed {  // scope guard: records the closing event on every exit path
+    Engine& E;
+    Section sec;
+    Timed(Engine& e, int label) : E(e) {
+      sec.label = label;
+      sec.e0 = E.tm_event();
+      sec.e1 = E.tm_event();
+      (void)hipEventRecord(sec.e0, E.stream);
+    }
+    ~Timed() {
+      (void)hipEventRecord(sec.e1, E.stream);
+      E.tm_open.push_back(sec);
+    }
+  };
+  void harvest_timers() {  // the stream must have been synchronised
+    for (const Section& sc : tm_open) {
+      float ms = 0.0f;
+      if (hipEventElapsedTime(&ms, sc.e0, sc.e1) == hipSuccess) {
+        tm_total[sc.label] += ms;
+        tm_sumsq[sc.label] += (double)ms * ms;
+        tm_calls[sc.label]++;
+      }
+      tm_pool.push_back(sc.e0);
+      tm_pool.push_back(sc.e1);
+    }
+    tm_open.clear();
+  }
+
   // ------------------------------------------------------------------ memory
   double* dalloc(long n) {
     void* p = nullptr;
@@ -180,6 +223,10 @@ struct Engine {
     if (h_res) { (void)hipHostFree(h_res); h_res = nullptr; }
     if (h_cgs) { (void)hipHostFree(h_cgs); h_cgs = nullptr; }
     if (cg_ev) { (void)hipEventDestroy(cg_ev); cg_ev = nullptr; }
+    for (const Section& sc : tm_open) { (void)hipEventDestroy(sc.e0); (void)hipEventDestroy(sc.e1); }
+    tm_open.clear();
+    for (hipEvent_t e : tm_pool) (void)hipEventDestroy(e);
+    tm_pool.clear();
     if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; }
     delete tab;
     tab = nullptr;
@@ -1117,6 +1164,7 @@ struct Engine {
 
   int tentative_solve(int i) {
     if (i < 1 || i >= s) throw std::string("stage out of range");
+    Timed tm_(*this, T_TENT);
     const double gamma = cfg.a_impl[i * s + i] * cfg.dt;
     ensure_dinv(i, gamma);
     std::vector<double> cq, cb;
@@ -1558,6 +1606,7 @@ struct Engine {
   // stage i of the IMEX scheme without the projection method (hdg_imex.py:600-620)
   int unsplit_solve(int i) {
     if (i < 1 || i >= s) throw std::string("stage out of range");
+    Timed tm_(*this, T_UNSPLIT);
     const double gamma = cfg.a_impl[i * s + i] * cfg.dt;
     ensure_dinv(i, gamma);
     const int ps = get_pset(cfg.tau / gamma);
@@ -1574,6 +1623,7 @@ struct Engine {
   }
 
   int pressure_solve(int key) {
+    Timed tm_(*this, T_PRESS);
     int its;
     if (key >= 1) {
       if (key >= s) throw std::string("stage out of range");
@@ -1626,9 +1676,10 @@ struct Engine {
     shift(curP, curL);
   }
   void step() {
+    Timed tm_(*this, T_STEP);
     begin_step();
     for (int i = 1; i < s; i++) {
-      bdm(stQ[i - 1], Qstar[i - 1]);
+      { Timed tb_(*this, T_BDM); bdm(stQ[i - 1], Qstar[i - 1]); }
       if (cfg.use_projection) {
         for (int r = 0; r < cfg.n_richardson; r++) {
           tentative_solve(i);
@@ -1647,9 +1698,10 @@ struct Engine {
   }
   // hdg_implicit.py:92-190 with use_projection_method=True.  Uses stage slot 0 for Q, slot 0 forcing.
   void implicit_step(int* its_t, int* its_p) {
+    Timed tm_(*this, T_STEP);
     const double dtt = cfg.dt;
     ensure_dinv(0, dtt);
-    bdm(curQ, Qstar[0]);                                         // hdg_implicit.py:98
+    { Timed tb_(*this, T_BDM); bdm(curQ, Qstar[0]); }             // hdg_implicit.py:98
     if (!cfg.use_projection) {
       // monolithic (u, phi, lambda) solve, hdg_implicit.py:153-186; fresh Function -> zero guess
       const int ps = get_pset(cfg.tau / dtt);
@@ -1658,7 +1710,8 @@ struct Engine {
       zero(fg_b.p, NPv); zero(fg_b.l, NLv);
       V3 x{updU, updP, updL};
       zero(updU, NQ); zero(updP, NPv); zero(updL, NLv);
-      int it = fgmres(Qstar[0], dtt, 0, ps, fg_b, x);
+      int it;
+      { Timed tu_(*this, T_UNSPLIT); it = fgmres(Qstar[0], dtt, 0, ps, fg_b, x); }
       copy(curQ, updU, NQ); copy(curP, updP, NPv); copy(curL, updL, NLv);
       shift(curP, curL);
       if (its_t) *its_t = it;
@@ -1668,13 +1721,20 @@ struct Engine {
     // rhs lives in updU: wQ1..wQ4 are scratch of GMRES and its preconditioner
     lincomb(NQ, {{curQ, 1.0}, {bvec(0), dtt * bscale[0]}}, updU);  // (Q,w) + dt (f,w)
     zero(Qtent[0], NQ);
-    int it1 = cfg.tent_solver == 0 ? gmres(Qstar[0], dtt, 0, updU, Qtent[0])   // hdg_implicit.py:103-129
-                                   : cheb_gmres(Qstar[0], dtt, 0, updU, Qtent[0]);
-    weak_div(Qtent[0], -1.0 / dtt, wP1, true);                   // hdg_implicit.py:145
-    condense(nullptr, wP1, nullptr, wL1);
-    zero(updL, NLv);
-    int it2 = trace_cg(wL1, updL);
-    backsub(nullptr, wP1, updL, updU, updP);
+    int it1, it2;
+    {
+      Timed tt_(*this, T_TENT);
+      it1 = cfg.tent_solver == 0 ? gmres(Qstar[0], dtt, 0, updU, Qtent[0])   // hdg_implicit.py:103-129
+                                 : cheb_gmres(Qstar[0], dtt, 0, updU, Qtent[0]);
+    }
+    {
+      Timed tp_(*this, T_PRESS);
+      weak_div(Qtent[0], -1.0 / dtt, wP1, true);                 // hdg_implicit.py:145
+      condense(nullptr, wP1, nullptr, wL1);
+      zero(updL, NLv);
+      it2 = trace_cg(wL1, updL);
+      backsub(nullptr, wP1, updL, updU, updP);
+    }
     lincomb(NQ, {{Qtent[0], 1.0}, {updU, dtt}}, curQ);           // hdg_implicit.py:150
     copy(curP, updP, NPv);
     copy(curL, updL, NLv);
@@ -1818,6 +1878,7 @@ static std::string g_create_error;
     if (_le != hipSuccess) { (h)->err = std::string("HIP: ") + hipGetErrorString(_le); return HDG_ERR_HIP; } \
     _le = hipGetLastError();                                                  \
     if (_le != hipSuccess) { (h)->err = std::string("HIP launch: ") + hipGetErrorString(_le); return HDG_ERR_HIP; } \
+    E.harvest_timers();                                                       \
     return HDG_OK;                                                            \
   } catch (const hdg::HipError& e) { (h)->err = e.msg; if (E.comm) E.comm->failed = true; return HDG_ERR_HIP; \
   } catch (const hdg::NotConverged& e) { (h)->err = e.msg; return HDG_ERR_NOT_CONVERGED; \
@@ -1947,7 +2008,7 @@ int hdg_reconstruct_trace(hdg_handle* h) {
 int hdg_project_bdm(hdg_handle* h, int src_stage, int dst) {
   HDG_API_BEGIN(h)
   if (src_stage < 0 || src_stage >= E.s || dst < 0 || dst >= (int)E.Qstar.size()) throw std::string("bad stage index");
-  E.bdm(E.stQ[src_stage], E.Qstar[dst]);
+  { hdg::Engine::Timed tb_(E, hdg::Engine::T_BDM); E.bdm(E.stQ[src_stage], E.Qstar[dst]); }
   HDG_API_END(h)
 }
 int hdg_project_bdm_nodal(hdg_handle* h, const double* Qin, double* Qout) {
@@ -2025,6 +2086,18 @@ int hdg_get_iteration_stats(hdg_handle* h, double* sums, long* counts, int reset
     if (sums) sums[i] = E.it_sum[i];
     if (counts) counts[i] = E.it_cnt[i];
     if (reset) { E.it_sum[i] = 0; E.it_cnt[i] = 0; }
+  }
+  HDG_API_END(h)
+}
+int hdg_get_timers(hdg_handle* h, double* total_ms, double* sumsq_ms, long* ncalls, int reset) {
+  HDG_API_BEGIN(h)
+  if (hipStreamSynchronize(E.stream) != hipSuccess) throw hdg::HipError{"hipStreamSynchronize failed"};
+  E.harvest_timers();
+  for (int i = 0; i < HDG_N_TIMERS; i++) {
+    if (total_ms) total_ms[i] = E.tm_total[i];
+    if (sumsq_ms) sumsq_ms[i] = E.tm_sumsq[i];
+    if (ncalls) ncalls[i] = E.tm_calls[i];
+    if (reset) { E.tm_total[i] = 0; E.tm_sumsq[i] = 0; E.tm_calls[i] = 0; }
   }
   HDG_API_END(h)
 }

@@ -140,6 +140,7 @@ class IncompressibleEulerHDGIMEX(IncompressibleEuler):
                   self.niter_pressure_reconstruction):
             a.reset()
         eng.iteration_stats(reset=True)
+        eng.timers(reset=True)
         for callback in self.callbacks:
             callback.reset()
             Q, p, _ = eng.get_field(_lib.HDG_STATE_CURRENT, lam=False)
@@ -180,6 +181,11 @@ class IncompressibleEulerHDGIMEX(IncompressibleEuler):
                 for callback in self.callbacks:
                     callback(Function(self._V_Q, Q, "Q"), Function(self._V_p, p, "p"), tn + self._dt, q_tracer=None)
         if fused:
+            # per-solve breakdown of the fused steps from the engine's device-side timers (same labels as the
+            # host timers of the per-solve path; "timestep" is already timed on the host)
+            for label, (n, tot, sq) in eng.timers(reset=True).items():
+                if label != "timestep" and n:
+                    PerformanceLog.add_aggregate(label, n, tot, sq)
             sums, cnt = eng.iteration_stats()
             for a, sm, c in zip((self.niter_tentative, self.niter_pressure, self.niter_final_pressure,
                                  self.niter_pressure_reconstruction), sums, cnt):

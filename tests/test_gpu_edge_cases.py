@@ -180,3 +180,45 @@ def test_alternative_trace_solver_paths_agree(hip_lib, tmp_path):
         for name in ("Q", "p", "lam"):
             assert _rel(res[tag][name], res["default"][name]) < 1e-9, (tag, name)
         assert np.all(np.abs(res[tag]["its"][1:] - res["default"]["its"][1:]) <= 1.0), tag
+
+
+def test_section_timers_across_the_abi(hip_lib):
+    """hdg_get_timers: the reference's PerformanceLog labels (logging.py:34-60; hdg_imex.py:257,274,551,564) for a
+    fused step -- call counts follow the loop structure (s-1 projections, (s-1) R tentative solves, (s-1) R + 2
+    mixed-Poisson solves per step), the parts add up to no more than the whole, and log_summary prints them."""
+    import io
+
+    from incompressibleeulerhdg_amd.auxilliary.logging import PerformanceLog, log_summary
+    from incompressibleeulerhdg_amd.mesh import UnitSquareMesh
+    from incompressibleeulerhdg_amd.model_problems import TaylorGreen
+    from incompressibleeulerhdg_amd.timesteppers import IncompressibleEulerHDGIMEXSSP2_332
+
+    nx, k, nsteps = 32, 2, 3
+    dt = 0.25 / nx
+    PerformanceLog.reset()
+    ts = IncompressibleEulerHDGIMEXSSP2_332(UnitSquareMesh(nx, nx), k, dt, n_richardson=2)
+    mp = TaylorGreen(ts._V_Q, ts._V_p)
+    e = ts._engine
+    e.set_state(ts._V_Q.interpolate(mp.Q_stationary), ts._V_p.interpolate(mp.p_stationary))
+    e.reconstruct_trace()
+    e.set_forcing_profile(mp.f_rhs().profile)
+    e.timers(reset=True)
+    for n in range(nsteps):
+        for sl in range(4):
+            e.set_forcing_scale(sl, -0.5)
+        e.step()
+    t = e.timers()
+    assert t["timestep"][0] == nsteps and t["bdm_projection"][0] == 2 * nsteps
+    assert t["tentative_velocity_solve"][0] == 4 * nsteps and t["pressure_solve"][0] == 6 * nsteps
+    assert t["unsplit_solve"][0] == 0
+    parts = t["bdm_projection"][1] + t["tentative_velocity_solve"][1] + t["pressure_solve"][1]
+    assert 0 < parts <= t["timestep"][1] * 1.001
+    assert parts > 0.5 * t["timestep"][1]  # the three sections are the bulk of a step
+    assert e.timers(reset=True)["timestep"][0] == nsteps and e.timers()["timestep"][0] == 0
+    # the class surface feeds them to the reference's summary table when the steps are fused
+    ts.solve(*mp.initial_condition(), None, mp.f_rhs(), 2 * dt, fused=True)
+    buf = io.StringIO()
+    log_summary(file=buf)
+    out = buf.getvalue()
+    for label in ("timestep", "bdm_projection", "tentative_velocity_solve", "pressure_solve"):
+        assert label in out, out

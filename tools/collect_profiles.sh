@@ -1,10 +1,34 @@
+#!/bin/bash
 # usage (on the GPU box, repo root): bash tools/collect_profiles.sh TAG
-# kernel stats, the two PMC passes (separate runs, as the guide prescribes) and the default bench line
-set -e
+# Kernel stats, HBM-traffic PMC passes (FETCH_SIZE and WRITE_SIZE in SEPARATE runs, counters without any other trace
+# domain, the program itself after `--`: /opt/skills/guides/MI355X_MICROARCH.md, HBM / rocprofv3 PMC slots) and the
+# matrix-core counters of the k = 3, 4 kernels.  tools/summarise_profiles.py turns the raw CSVs under gpurun_out/ into
+# the tracked files profiles/<TAG>_* and profiles/pmc_traffic.json (tagged with the hash of the kernel sources).
 TAG=$1
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -o s -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_stats.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof_${TAG}_fetch -o f -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/prof_${TAG}_write -o w -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_write.log 2>&1
-python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
-tail -c 600 gpurun_out/${TAG}_bench.json
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/prof_$TAG
+rm -rf $O && mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+B="python3 $R/bench.py --no-cpu-baseline"
+T="python3 $R/tools/time_kernels.py"
+# C3: kernel stats of the benchmark itself
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/c3_stats -o s -- $B --steps 5 --warmup 1 > $O/c3_stats.log 2>&1
+# C3: HBM traffic of the kernels inside the benchmark (2 timed steps), separate passes
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/c3_fetch -o f -- $B --steps 2 --warmup 1 > $O/c3_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/c3_write -o w -- $B --steps 2 --warmup 1 > $O/c3_write.log 2>&1
+# calibration of FETCH_SIZE / WRITE_SIZE on a kernel with a known byte count (stream triad on velocity vectors)
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/cal_fetch -o f -- $T 2 1024 8 > $O/cal_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/cal_write -o w -- $T 2 1024 8 > $O/cal_write.log 2>&1
+# k = 3, 4 at 512^2: kernel stats and matrix-core counters
+for K in 3 4; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/k${K}_stats -o s -- $B --degree $K --nx 512 --steps 3 --warmup 1 > $O/k${K}_stats.log 2>&1
+  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_MFMA SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/k${K}_mfma -o m -- $B --degree $K --nx 512 --steps 2 --warmup 1 > $O/k${K}_mfma.log 2>&1
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/k${K}_fetch -o f -- $B --degree $K --nx 512 --steps 2 --warmup 1 > $O/k${K}_fetch.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/k${K}_write -o w -- $B --degree $K --nx 512 --steps 2 --warmup 1 > $O/k${K}_write.log 2>&1
+done
+cd $R
+python3 bench.py > $O/bench_c3.json 2> $O/bench_c3.err
+python3 bench.py --degree 3 --nx 512 --no-cpu-baseline > $O/bench_k3.json 2> $O/bench_k3.err
+python3 bench.py --degree 4 --nx 512 --no-cpu-baseline > $O/bench_k4.json 2> $O/bench_k4.err
+find $O -name "*.csv" | head -50
+tail -c 400 $O/bench_c3.json

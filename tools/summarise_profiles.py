@@ -1,0 +1,110 @@
+"""Turn the raw rocprofv3 output of tools/collect_profiles.sh (gpurun_out/prof_TAG/) into the tracked summaries
+profiles/TAG_* and profiles/pmc_traffic.json.  usage: python tools/summarise_profiles.py TAG"""
+import collections, csv, glob, json, os, shutil, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+tag = sys.argv[1]
+src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+dst = os.path.join(ROOT, "profiles")
+
+
+def find(sub, pat):
+    g = glob.glob(os.path.join(src, sub, "**", pat), recursive=True)
+    return g[0] if g else None
+
+
+def short(name):
+    n = name.replace("void ", "").replace("hdg::", "")
+    return n.split("(")[0].strip()
+
+
+def per_kernel(path):
+    """average counter value per dispatch and kernel"""
+    acc = collections.defaultdict(lambda: collections.defaultdict(float))
+    disp = collections.defaultdict(set)
+    for r in csv.DictReader(open(path)):
+        k = short(r["Kernel_Name"])
+        acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        disp[k].add(r["Dispatch_Id"])
+    return {k: dict({c: v / len(disp[k]) for c, v in acc[k].items()}, launches=len(disp[k])) for k in acc}
+
+
+def write_counter_csv(path, table):
+    cols = sorted({c for v in table.values() for c in v})
+    with open(path, "w") as f:
+        f.write("kernel," + ",".join(cols) + "\n")
+        for k, v in sorted(table.items(), key=lambda kv: -kv[1].get("launches", 0)):
+            f.write('"' + k + '",' + ",".join(f"{v.get(c, 0):.6g}" for c in cols) + "\n")
+
+
+out = {}
+for cfg in ("c3", "k3", "k4"):
+    st = find(f"{cfg}_stats", "*kernel_stats.csv")
+    if st:
+        shutil.copy(st, os.path.join(dst, f"{tag}_{cfg}_kernel_stats.csv"))
+    tabs = {}
+    for what in ("fetch", "write", "mfma"):
+        f = find(f"{cfg}_{what}", "*counter_collection.csv")
+        if f:
+            tabs[what] = per_kernel(f)
+            write_counter_csv(os.path.join(dst, f"{tag}_{cfg}_pmc_{what}.csv"), tabs[what])
+    out[cfg] = tabs
+    b = os.path.join(src, f"bench_{cfg}.json")
+    if os.path.exists(b) and os.path.getsize(b) > 0:
+        shutil.copy(b, os.path.join(dst, f"{tag}_bench_{cfg}.json"))
+
+# calibration: stream triad y = a x + b y on velocity vectors, 2 reads + 1 write of 8 N_Q bytes each
+cal = {}
+for what, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+    f = find(f"cal_{what}", "*counter_collection.csv")
+    if f:
+        t = per_kernel(f)
+        k = [n for n in t if n.startswith("k_axpby")]
+        if k:
+            cal[ctr] = t[k[0]][ctr]
+NQ_C3 = 41943040 + 2 * 2 * 10 * 2 * 1024  # velocity vector incl. the two ghost rows
+triad_read_KiB, triad_write_KiB = 2 * 8 * NQ_C3 / 1024, 8 * NQ_C3 / 1024
+f_fetch = triad_read_KiB / cal["FETCH_SIZE"] if "FETCH_SIZE" in cal else 2.0
+f_write = triad_write_KiB / cal["WRITE_SIZE"] if "WRITE_SIZE" in cal else 1.0
+# the guide's factors: 2 (FETCH_SIZE of 16-byte-per-lane streams), 1 (WRITE_SIZE); use the guide's values, report ours
+FF, FW = 2.0, 1.0
+
+import bench  # csrc_sha16
+
+traffic = {"csrc_sha16": bench.csrc_sha16(), "tag": tag,
+           "calibration": {"kernel": "k_axpby (stream triad on velocity vectors)", "FETCH_SIZE_KiB": cal.get("FETCH_SIZE"),
+                           "WRITE_SIZE_KiB": cal.get("WRITE_SIZE"), "algorithmic_read_KiB": triad_read_KiB,
+                           "algorithmic_write_KiB": triad_write_KiB, "measured_factor_fetch": f_fetch,
+                           "measured_factor_write": f_write, "applied_factor_fetch": FF, "applied_factor_write": FW,
+                           "note": "FETCH_SIZE counts 64 B per 128-B request on gfx950 (guide: MI355X_MICROARCH.md, HBM): doubled; "
+                                   "WRITE_SIZE exact; both in KiB; Infinity-Cache hits are counted, so this is fabric traffic, "
+                                   "an upper bound on HBM bytes"},
+           "configs": {}}
+names = {"adv": ("k_adv_apply<", "k_adv_mfma<"), "lift": ("k_edge_lift<", "k_edge_lift_mfma<")}
+for cfg, (nx, k) in (("c3", (1024, 2)), ("k3", (512, 3)), ("k4", (512, 4))):
+    tabs = out.get(cfg, {})
+    if "fetch" not in tabs or "write" not in tabs:
+        continue
+    kern = {}
+    for kname, row in tabs["fetch"].items():
+        w = tabs["write"].get(kname, {})
+        kern[kname] = {"FETCH_SIZE_KiB": row.get("FETCH_SIZE", 0.0), "WRITE_SIZE_KiB": w.get("WRITE_SIZE", 0.0),
+                       "hbm_bytes": 1024.0 * (FF * row.get("FETCH_SIZE", 0.0) + FW * w.get("WRITE_SIZE", 0.0)),
+                       "launches": row["launches"]}
+    entry = {"workload": {"nx": nx, "degree": k}, "kernels": kern}
+    if "mfma" in tabs:
+        m = {}
+        for kname, row in tabs["mfma"].items():
+            if row.get("SQ_INSTS_MFMA", 0) > 0:
+                cyc = row["GRBM_GUI_ACTIVE"] / 8.0  # the counter is summed over the 8 XCDs
+                m[kname] = dict(row, mfma_busy_frac=row["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 1024.0))  # 1024 SIMDs
+        entry["mfma"] = m
+    traffic["configs"][cfg] = entry
+json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
+print(json.dumps(traffic["calibration"], indent=1))
+for cfg, e in traffic["configs"].items():
+    for kname, row in sorted(e["kernels"].items(), key=lambda kv: -kv[1]["hbm_bytes"] * kv[1]["launches"])[:6]:
+        print(cfg, kname, f"{row['hbm_bytes'] / 1e6:.1f} MB/launch x {row['launches']}")
+    for kname, row in e.get("mfma", {}).items():
+        print(cfg, "MFMA", kname, f"busy {row['mfma_busy_frac']:.3f}")
