@@ -121,13 +121,23 @@ def roofline_block(eng, args, nx, k, world):
                                     ("k_backsub<K>", 3, 20, 8.0 * (NL + 2 * NQ + 2 * NP))):
         ms = eng.time_kernel(kid, reps)
         others[name] = dict(ms=ms, GBs=gbs(nbytes, ms), algorithmic_bytes=nbytes)
-    pmc = {}
-    try:  # HBM bytes per launch from PMC passes -- only if they were measured on THIS code and workload
+    pmc, pmc_mfma = {}, {}
+    try:  # HBM bytes per launch (and matrix-core busy fractions) from the committed PMC passes -- used only if they
+        # were measured on THIS code (hash of the kernel sources) and this workload; otherwise traffic is null
         tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        if tj.get("csrc_sha16") == csrc_sha16() and tj.get("workload") == {"nx": nx, "degree": k} and world == 1:
-            pmc = tj["kernels"]
+        if tj.get("csrc_sha16") == csrc_sha16() and world == 1:
+            for cfg in tj["configs"].values():
+                if cfg["workload"] == {"nx": nx, "degree": k}:
+                    kn = cfg["kernels"]
+                    for key, names in (("adv", (f"k_adv_apply<{k}>", f"k_adv_mfma<{k}>")),
+                                       ("lift", (f"k_edge_lift<{k}, false, 2>", f"k_edge_lift_mfma<{k}>"))):
+                        for nm in names:
+                            if nm in kn and (k <= 2) == ("mfma" not in nm):
+                                pmc[key] = kn[nm]["hbm_bytes"]
+                            if nm in cfg.get("mfma", {}):
+                                pmc_mfma[key] = cfg["mfma"][nm]["mfma_busy_frac"]
     except Exception:
-        pmc = {}
+        pmc, pmc_mfma = {}, {}
     if not mfma:
         kid_lift = (6 if hybrid else 4) if cheb else (9 if hybrid else 4)
         ms_lift = eng.time_kernel(kid_lift, 20)
@@ -161,37 +171,48 @@ def roofline_block(eng, args, nx, k, world):
     ms_lift = eng.time_kernel(9, 20)
     tf = lambda fl, ms: fl / (ms * 1e-3) / 1e12
     others[f"k_edge_lift_mfma<{k}>"] = dict(ms=ms_lift, TFLOPs=tf(lift_alg, ms_lift), mfma_util=tf(lift_issued, ms_lift) / FP64_MATRIX_PEAK_TF,
-                                             GBs=gbs(8.0 * 2 * NQ, ms_lift), algorithmic_bytes=8.0 * 2 * NQ, traffic=pmc.get("lift"))
+                                             GBs=gbs(8.0 * 2 * NQ, ms_lift), algorithmic_bytes=8.0 * 2 * NQ, traffic=pmc.get("lift"),
+                                             mfma_busy_pmc=pmc_mfma.get("lift"))
     return dict(bound="mfma", kernel=f"k_adv_mfma<{k}>", achieved=tf(adv_alg, ms_adv), peak=FP64_MATRIX_PEAK_TF, unit="TFLOP/s",
                 frac=tf(adv_alg, ms_adv) / FP64_MATRIX_PEAK_TF, mfma_util=tf(adv_issued, ms_adv) / FP64_MATRIX_PEAK_TF,
+                mfma_busy_pmc=pmc_mfma.get("adv"),  # SQ_VALU_MFMA_BUSY_CYCLES / (kernel cycles x 1024 SIMDs), profiles/pmc_traffic.json
                 algorithmic_flops=adv_alg, issued_mfma_flops=adv_issued, ms_per_launch=ms_adv, traffic=pmc.get("adv"),
                 hbm_GBs=gbs(8.0 * 3 * NQ, ms_adv), algorithmic_bytes=8.0 * 3 * NQ, stream_triad_GBs=triad, other_kernels=others)
 
 
-def cpu_baseline(degree, budget_s=20.0):
-    """Time the CPU oracle (scipy sparse direct solves: the converged limit of the reference's
-    assembled-AIJ + LU/ILU solver stack) on the largest mesh whose single step fits the budget."""
-    from oracle import hdg_oracle as orc
+def cpu_baseline(degree, nx_sample=None):
+    """The C++/OpenMP CPU twin (oracle/cpu_twin: same discretisation, same solver algorithms and tolerances as the
+    engine, written for CPUs; a stand-in for the Firedrake/PETSc path, which cannot be run here) timed on all host
+    cores of this box on a bounded sample of the same scheme: same tableau, R, flux, Taylor-Green data and
+    dt = 0.25/nx, on a smaller mesh (1 warm-up + 2 timed steps)."""
+    from oracle.cpu_twin import CpuTwin
+    from oracle.hdg_oracle import TABLEAUX
 
-    best = None
-    for nx in (8, 16, 32, 64):
-        d = orc.HDGDiscretisation(nx, degree)
-        tg = orc.TaylorGreen(d)
-        dt = 0.25 / nx
-        o = orc.OracleHDGIMEX(d, dt, "imex_ssp2_332")
-        o.set_initial_condition(*tg.initial_condition())
-        o.step(tg.f_rhs, 0.0)  # warm-up step (mirrors --warmup, driver.py:157-162)
-        t0 = time.perf_counter()
-        nsteps = 2
-        for n in range(nsteps):
-            o.step(tg.f_rhs, (n + 1) * dt)
-        el = time.perf_counter() - t0
-        best = dict(value=d.N * nsteps / el / 1e6, unit="million DOF-updates/s", cores=1, kind="port",
-                    sample=f"oracle (numpy/scipy sparse LU) HDG-IMEX SSP2(3,3,2) k={degree} nx={nx}, "
-                           f"1 warm-up + {nsteps} timed steps, {el:.1f} s")
-        if el * 5 > budget_s:  # the next mesh is 4x the unknowns and >4x the factorisation time
-            break
-    return best
+    nx = nx_sample or (256 if degree <= 2 else 128)
+    dt, kappa = 0.25 / nx, 0.5
+    tb = TABLEAUX["imex_ssp2_332"]
+    t = CpuTwin(nx=nx, degree=degree, dt=dt, nstages=3, a_expl=tb["a_expl"], a_impl=tb["a_impl"], b_expl=tb["b_expl"],
+                b_impl=tb["b_impl"], c_expl=tb["c_expl"])
+    xq, xp = t.node_coordinates()
+    S = lambda z: np.sin((z - 0.5) * np.pi)
+    Cc = lambda z: np.cos((z - 0.5) * np.pi)
+    Qs = np.stack([-Cc(xq[:, 0]) * S(xq[:, 1]), S(xq[:, 0]) * Cc(xq[:, 1])], axis=-1)
+    ps = (S(xp[:, 0]) ** 2 + S(xp[:, 1]) ** 2) / 2
+    t.set_state(Qs, ps)
+    t.reconstruct_trace()
+    t.set_forcing_profile(Qs)
+    t.run_separable(ssp2_scales(1, dt, kappa))  # warm-up step (mirrors --warmup, driver.py:157-162)
+    t.iteration_stats(reset=True)
+    nsteps = 2
+    t0 = time.perf_counter()
+    t.run_separable(ssp2_scales(nsteps, dt, kappa, t0=dt))
+    el = time.perf_counter() - t0
+    sums, cnt = t.iteration_stats()
+    its = [float(a / max(b, 1)) for a, b in zip(sums, cnt)]
+    return dict(value=t.n_total * nsteps / el / 1e6, unit="million DOF-updates/s", cores=t.threads, kind="port",
+                sample=f"C++/OpenMP twin (oracle/cpu_twin), HDG-IMEX SSP2(3,3,2) R=2 upwind k={degree} nx={nx} "
+                       f"({t.n_total} unknowns), {t.threads} threads, 1 warm-up + {nsteps} timed steps in {el:.1f} s; "
+                       f"Krylov iterations tentative/pressure {its[0]:.1f}/{its[1]:.1f} (GMRES(8) / PCG)")
 
 
 def main():

@@ -60,7 +60,7 @@ for what, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
     f = find(f"cal_{what}", "*counter_collection.csv")
     if f:
         t = per_kernel(f)
-        k = [n for n in t if n.startswith("k_axpby")]
+        k = [n for n in t if n.startswith("k_axpby<true>")]  # the velocity-sized launches (streaming cache policy)
         if k:
             cal[ctr] = t[k[0]][ctr]
 NQ_C3 = 41943040 + 2 * 2 * 10 * 2 * 1024  # velocity vector incl. the two ghost rows
