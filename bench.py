@@ -188,7 +188,7 @@ def cpu_baseline(degree, nx_sample=None):
     from oracle.cpu_twin import CpuTwin
     from oracle.hdg_oracle import TABLEAUX
 
-    nx = nx_sample or (256 if degree <= 2 else 128)
+    nx = nx_sample or (512 if degree <= 2 else 256)  # about 10-30 s of work on the 16 cores of a one-GPU box
     dt, kappa = 0.25 / nx, 0.5
     tb = TABLEAUX["imex_ssp2_332"]
     t = CpuTwin(nx=nx, degree=degree, dt=dt, nstages=3, a_expl=tb["a_expl"], a_impl=tb["a_impl"], b_expl=tb["b_expl"],

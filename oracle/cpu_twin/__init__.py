@@ -34,6 +34,22 @@ def build(force=False, verbose=False):
     return LIB_PATH
 
 
+def host_threads():
+    """Threads the twin may use: HDG_CPU_THREADS, else the CPUs this process is allowed to run on (affinity mask and
+    cgroup quota), capped at 16 -- the CPU share of a one-GPU box.  OpenMP's own default (every core it can see) would
+    oversubscribe a container that is limited to a share of the machine."""
+    if os.environ.get("HDG_CPU_THREADS"):
+        return max(1, int(os.environ["HDG_CPU_THREADS"]))
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
 def load():
     global _lib
     if _lib is None:
@@ -41,6 +57,7 @@ def load():
         _lib = C.CDLL(LIB_PATH)
         _lib.hdgcpu_last_error.restype = C.c_char_p
         _lib.hdgcpu_last_error.argtypes = [C.c_void_p]
+        _lib.hdgcpu_set_num_threads(C.c_int(host_threads()))
     return _lib
 
 

@@ -869,6 +869,7 @@ int hdgcpu_create(const hdg_config* cfg, Handle** out) {
 int hdgcpu_destroy(Handle* h) { if (!h) return HDG_ERR_ARG; delete h->t; delete h; return HDG_OK; }
 const char* hdgcpu_last_error(const Handle* h) { return h ? h->err.c_str() : g_err.c_str(); }
 int hdgcpu_num_threads() { return omp_get_max_threads(); }
+void hdgcpu_set_num_threads(int n) { if (n > 0) omp_set_num_threads(n); }
 int hdgcpu_get_sizes(const Handle* h, long* n_cells, long* n_edges, int* n_u, int* n_p, int* n_l) {
   if (!h || !h->t) return HDG_ERR_ARG;
   *n_cells = h->t->ncell; *n_edges = h->t->nedge; *n_u = h->t->NU; *n_p = h->t->NP; *n_l = h->t->NL;

@@ -29,7 +29,7 @@ def test_operators_match_the_cpu_twin_on_large_meshes(hip_lib, k, nx):
     e, t, _ = _pair(k, nx)
     xq, xp = e.node_coordinates()
     tq, tp = t.node_coordinates()
-    assert np.array_equal(xq, tq) and np.array_equal(xp, tp)
+    assert np.allclose(xq, tq, rtol=0, atol=1e-14) and np.allclose(xp, tp, rtol=0, atol=1e-14)
     rng = np.random.default_rng(31)
     Q, x, lam = rng.standard_normal(e.shape_Q), rng.standard_normal(e.shape_Q), rng.standard_normal(e.shape_l)
     Px = e.project_bdm_nodal(Q)
