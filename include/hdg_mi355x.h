@@ -164,6 +164,33 @@ int hdg_get_iteration_stats(hdg_handle* h, double* sums, long* counts, int reset
 #define HDG_N_TIMERS 5
 int hdg_get_timers(hdg_handle* h, double* total_ms, double* sumsq_ms, long* ncalls, int reset);
 
+/* ---- passive tracer.  Explicit DG transport of a scalar in DG_k by the L2 projection of
+ * the stage velocity onto [CG_{k+1}]^2 (common.py:110-129): q_i = q_0 + dt sum_{j<i} a_expl[i,j] M^-1 T(q_j, P(Q_i))
+ * after every stage (hdg_imex.py:415-431,622-623), q^{n+1} = q_0 + dt sum_i b_expl[i] M^-1 T(q_i, P(Q_i)) at the end of
+ * the step (:433-448,638-639); hdg_implicit.py:93-96,192-193: q^{n+1} = q^n + dt M^-1 T(q^n, P(Q^n)).
+ * hdg_set_tracer(h, q) switches the tracer on (q: nodal DG_k values, pressure layout; NULL switches it off); hdg_step /
+ * hdg_run_separable / hdg_implicit_step then carry it along; the three step-level calls serve the per-solve loop. */
+int hdg_set_tracer(hdg_handle* h, const double* q);
+int hdg_get_tracer(hdg_handle* h, double* q);
+int hdg_tracer_begin_step(hdg_handle* h);        /* self._q[0].assign(q_tracer), hdg_imex.py:560 */
+int hdg_tracer_stage(hdg_handle* h, int stage);  /* solve(a_tracer == self._tracer_residual(chi, i), self._q[i]), :622-623 */
+int hdg_tracer_finish_step(hdg_handle* h);       /* solve(a_tracer == self._tracer_final_residual(chi), q_tracer), :638-639 */
+/* test hook: out = M^-1 T(.; q, u) for nodal q (DG_k) and nodal velocity u; project != 0: u is projected onto CG first */
+int hdg_apply_tracer_advection(hdg_handle* h, const double* q, const double* u, int project, double* out);
+
+/* ---- continuous space CG_{k+1} (same node family as the broken velocity space)
+ * hdg_cg_size: number of dofs; hdg_cg_coordinates: their positions (n_cg, 2);
+ * hdg_cg_project_nodal: Function(V_CG).project(u) of common.py:119-122, returned as nodal values of the broken space;
+ * hdg_vorticity: the CG_{k+1} vorticity of AnimationCallback.vorticity_solver (callbacks.py:43-69) of the nodal
+ * velocity Q (NULL: the current state), n_cg values in dof order */
+int hdg_cg_size(hdg_handle* h, long* n_cg);
+int hdg_cg_coordinates(hdg_handle* h, double* xy);
+int hdg_cg_project_nodal(hdg_handle* h, const double* Qin, double* Qout);
+int hdg_vorticity(hdg_handle* h, const double* Q, double* omega);
+/* nodal values of a continuous function (n_cg values) on the broken node set of the velocity space, (N_c*n_u,):
+ * what the VTK writer needs to write a CG function next to the broken fields (callbacks.py:85) */
+int hdg_cg_to_broken(hdg_handle* h, const double* cg_values, double* broken);
+
 /* physical coordinates of the DG nodes, boundary numbering: xq (N_c*n_u, 2), xp (N_c*n_p, 2); what
  * `interpolate` evaluates expressions at (hdg_imex.py:520-521,555; model_problems.py:88-103) */
 int hdg_node_coordinates(hdg_handle* h, double* xq, double* xp);

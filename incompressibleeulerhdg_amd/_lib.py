@@ -118,6 +118,17 @@ SIGNATURES = {
     "hdg_implicit_step": [_h, _ip, _ip],
     "hdg_get_iteration_stats": [_h, _dp, _lp, C.c_int],
     "hdg_get_timers": [_h, _dp, _dp, _lp, C.c_int],
+    "hdg_set_tracer": [_h, _dp],
+    "hdg_get_tracer": [_h, _dp],
+    "hdg_tracer_begin_step": [_h],
+    "hdg_tracer_stage": [_h, C.c_int],
+    "hdg_tracer_finish_step": [_h],
+    "hdg_apply_tracer_advection": [_h, _dp, _dp, C.c_int, _dp],
+    "hdg_cg_size": [_h, _lp],
+    "hdg_cg_coordinates": [_h, _dp],
+    "hdg_cg_project_nodal": [_h, _dp, _dp],
+    "hdg_vorticity": [_h, _dp, _dp],
+    "hdg_cg_to_broken": [_h, _dp, _dp],
     "hdg_node_coordinates": [_h, _dp, _dp],
     "hdg_l2_norms": [_h, _dp, _dp, _dp, _dp],
     "hdg_integrate_pressure": [_h, _dp, _dp],
@@ -335,6 +346,59 @@ class Engine:
         cnt = np.zeros(4, dtype=np.int64)
         self._ck(self.lib.hdg_get_iteration_stats(self.h, _ptr(sums), cnt.ctypes.data_as(_lp), 1 if reset else 0))
         return sums, cnt
+
+    # --- passive tracer, continuous-space diagnostics
+    def set_tracer(self, q):
+        q = None if q is None else _arr(q, self.shape_p)
+        self._ck(self.lib.hdg_set_tracer(self.h, _ptr(q)))
+
+    def get_tracer(self):
+        q = np.empty(self.shape_p)
+        self._ck(self.lib.hdg_get_tracer(self.h, _ptr(q)))
+        return q
+
+    def tracer_begin_step(self):
+        self._ck(self.lib.hdg_tracer_begin_step(self.h))
+
+    def tracer_stage(self, i):
+        self._ck(self.lib.hdg_tracer_stage(self.h, int(i)))
+
+    def tracer_finish_step(self):
+        self._ck(self.lib.hdg_tracer_finish_step(self.h))
+
+    def apply_tracer_advection(self, q, u, project=True):
+        q, u = _arr(q, self.shape_p), _arr(u, self.shape_Q)
+        out = np.empty(self.shape_p)
+        self._ck(self.lib.hdg_apply_tracer_advection(self.h, _ptr(q), _ptr(u), 1 if project else 0, _ptr(out)))
+        return out
+
+    def cg_size(self):
+        n = C.c_long()
+        self._ck(self.lib.hdg_cg_size(self.h, C.byref(n)))
+        return n.value
+
+    def cg_coordinates(self):
+        xy = np.empty((self.cg_size(), 2))
+        self._ck(self.lib.hdg_cg_coordinates(self.h, _ptr(xy)))
+        return xy
+
+    def cg_project_nodal(self, Q):
+        Q = _arr(Q, self.shape_Q)
+        out = np.empty(self.shape_Q)
+        self._ck(self.lib.hdg_cg_project_nodal(self.h, _ptr(Q), _ptr(out)))
+        return out
+
+    def vorticity(self, Q=None):
+        Q = None if Q is None else _arr(Q, self.shape_Q)
+        out = np.empty(self.cg_size())
+        self._ck(self.lib.hdg_vorticity(self.h, _ptr(Q), _ptr(out)))
+        return out
+
+    def cg_to_broken(self, values):
+        values = _arr(values, (self.cg_size(),))
+        out = np.empty(self.n_cells * self.n_u)
+        self._ck(self.lib.hdg_cg_to_broken(self.h, _ptr(values), _ptr(out)))
+        return out
 
     TIMER_LABELS = ("timestep", "bdm_projection", "tentative_velocity_solve", "pressure_solve", "unsplit_solve")
 

@@ -1,0 +1,226 @@
+// Continuous Lagrange space CG_{k+1} on the structured triangulation, the passive-tracer transport operator and the
+// vorticity right-hand side (the callers either side of the hot path).
+//
+// Reference (paths relative to the reference's src/):
+//   timesteppers/common.py:110-129   _tracer_advection: u_ = L2 projection of the velocity onto [CG_{k+1}]^2, upwind DG
+//                                    transport form T(chi; q, u_)
+//   auxilliary/callbacks.py:43-69    vorticity in CG_{k+1} by an L2 projection of the weak curl of the broken velocity
+//
+// The continuous space shares the node family of the broken velocity space, so a continuous function is a broken one
+// whose coincident nodes agree.  Its dofs are attached to the grid corners like the trace space:
+//   vertex (i,j) | p-1 interior nodes of H(i,j), V(i,j), D(i,j) | (p-1)(p-2)/2 interior nodes of L(i,j), U(i,j)     p = k+1
+// in ONE contiguous vector [vertices | H | V | D | interiors].  A cell reaches its dofs through a small per-shape table
+// (CgTabs::fwd, built and cross-checked against node coordinates on the host); a dof gathers from its (at most six)
+// cells through the inverse table -- owner computes, no atomics, bitwise reproducible.
+// The mass matrix of the continuous space is never formed: apply = per cell (gather nodal values, local mass
+// Mloc = Vinv^T Vinv) -> per dof (sum over incident cells), solved by Jacobi-preconditioned CG.
+#pragma once
+#include "hdg_kernels.hpp"
+
+namespace hdg {
+
+struct CgTabs {
+  int p, nint;                 // polynomial degree k+1, interior nodes per cell
+  int nx, ny;
+  long baseH, baseV, baseD, baseI, ncg;
+  short fwd[2][21][4];         // [shape][local node] -> {type 0 vertex 1 H 2 V 3 D 4 interior, di, dj, t}
+  short vtx[6][4];             // vertex gathers from {shape, ci, cj, node}: cell (shape, i+ci, j+cj)
+  short edg[3][4][2][4];       // [H,V,D][t][entry] -> {shape, ci, cj, node}
+  short intr[2][6];            // interior dof q of shape s -> local node
+};
+
+__device__ __forceinline__ long cg_dof(const CgTabs& C, int type, int I, int J, int t, int s) {
+  switch (type) {
+    case 0: return (long)J * (C.nx + 1) + I;
+    case 1: return C.baseH + ((long)J * C.nx + I) * (C.p - 1) + t;
+    case 2: return C.baseV + ((long)J * (C.nx + 1) + I) * (C.p - 1) + t;
+    case 3: return C.baseD + ((long)J * C.nx + I) * (C.p - 1) + t;
+    default: return C.baseI + (((long)J * C.nx + I) * 2 + s) * C.nint + t;
+  }
+}
+
+// per cell.  MODE 0: y = Mloc * (nodal values gathered from the continuous vector cg)
+//            MODE 1: y = Vinv^T x_d          (x: broken velocity, modal; component d)   -> right-hand side of the projection
+//            MODE 2: x_d = Vinv * (nodal values gathered from cg)                        -> the projection, modal, component d
+//            MODE 3: y = Vinv^T w,  w_m = -int_K (d_x psi_m Q_y - d_y psi_m Q_x) + int_{dK on boundary} psi_m (n x Q)
+// y: scalar cell vector with NU planes y[n*Nc + c]
+template <int K, int MODE>
+__global__ __launch_bounds__(128) void k_cg_cell(Geo g, CgTabs C, DevTables T, const double* __restrict__ Mloc, const double* __restrict__ Vinv,
+                                                 const double* __restrict__ Wx0, const double* __restrict__ Wy0,
+                                                 const double* __restrict__ Wx1, const double* __restrict__ Wy1,
+                                                 const double* __restrict__ Eb, const double* __restrict__ cg,
+                                                 double* __restrict__ vel, int d, double* __restrict__ y) {
+  constexpr int NU = Dim<K>::NU;
+  HDG_CELL_PROLOGUE
+  double v[NU], o[NU];
+  if (MODE == 0 || MODE == 2) {
+#pragma unroll
+    for (int n = 0; n < NU; n++) {
+      const short* f = C.fwd[s][n];
+      v[n] = cg[cg_dof(C, f[0], i + f[1], j + f[2], f[3], s)];
+    }
+  } else if (MODE == 1) {
+#pragma unroll
+    for (int m = 0; m < NU; m++) v[m] = vel[vix<NU>(d * NU + m, g.Nc, c)];
+  }
+  if (MODE == 0) {
+#pragma unroll
+    for (int n = 0; n < NU; n++) o[n] = 0.0;
+    mv_acc<NU, NU>(Mloc, v, o, 1.0);
+  } else if (MODE == 1) {
+#pragma unroll
+    for (int n = 0; n < NU; n++) {
+      double acc = 0.0;
+#pragma unroll
+      for (int m = 0; m < NU; m++) acc = fma(Vinv[m * NU + n], v[m], acc);
+      o[n] = acc;
+    }
+  } else if (MODE == 2) {
+#pragma unroll
+    for (int m = 0; m < NU; m++) o[m] = 0.0;
+    mv_acc<NU, NU>(Vinv, v, o, 1.0);
+#pragma unroll
+    for (int m = 0; m < NU; m++) vel[vix<NU>(d * NU + m, g.Nc, c)] = o[m];
+    return;
+  } else {
+    double q[2 * NU], w[NU];
+    load_vel<NU>(vel, g.Nc, c, q);
+    const double* __restrict__ Wx = s == 0 ? Wx0 : Wx1;
+    const double* __restrict__ Wy = s == 0 ? Wy0 : Wy1;
+#pragma unroll
+    for (int m = 0; m < NU; m++) {
+      double acc = 0.0;
+#pragma unroll
+      for (int l = 0; l < NU; l++) acc += Wy[m * NU + l] * q[l] - Wx[m * NU + l] * q[NU + l];
+      w[m] = acc;
+    }
+#pragma unroll
+    for (int e = 0; e < 3; e++) {
+      long cn;
+      if (nbr(s, e, i, j, g, cn)) continue;
+      // boundary edge: + int_e psi_m (n_x Q_y - n_y Q_x), outward normal = sig * n_e
+      const double* __restrict__ E = Eb + ((size_t)s * 3 + e) * NU * NU;
+      const double nxo = T.sig[s][e] * T.enx[e], nyo = T.sig[s][e] * T.eny[e];
+#pragma unroll
+      for (int m = 0; m < NU; m++) {
+        double acc = 0.0;
+#pragma unroll
+        for (int l = 0; l < NU; l++) acc += E[m * NU + l] * (nxo * q[NU + l] - nyo * q[l]);
+        w[m] += acc;
+      }
+    }
+#pragma unroll
+    for (int n = 0; n < NU; n++) {
+      double acc = 0.0;
+#pragma unroll
+      for (int m = 0; m < NU; m++) acc = fma(Vinv[m * NU + n], w[m], acc);
+      o[n] = acc;
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < NU; n++) y[(long)n * g.Nc + c] = o[n];
+}
+
+// nodal values of a continuous function in the broken layout of the library boundary: out[cref*NU + n]
+template <int K>
+__global__ __launch_bounds__(128) void k_cg_to_broken(Geo g, CgTabs C, const double* __restrict__ cg, double* __restrict__ out) {
+  constexpr int NU = Dim<K>::NU;
+  HDG_CELL_PROLOGUE
+  const long cref = 2 * ((long)j * g.nx + i) + s;
+#pragma unroll
+  for (int n = 0; n < NU; n++) {
+    const short* f = C.fwd[s][n];
+    out[cref * NU + n] = cg[cg_dof(C, f[0], i + f[1], j + f[2], f[3], s)];
+  }
+}
+
+// per grid corner: every continuous dof attached to the corner = sum over its incident cells of y
+template <int K>
+__global__ __launch_bounds__(128) void k_cg_gather(Geo g, CgTabs C, const double* __restrict__ y, double* __restrict__ out) {
+  HDG_CORNER_PROLOGUE
+  auto cellval = [&](const short* f) -> double {
+    const int ci = i + f[1], cj = j + f[2];
+    if (ci < 0 || cj < 0 || ci >= g.nx || cj >= g.ny) return 0.0;
+    return y[(long)f[3] * g.Nc + cidx(g, f[0], cj, ci)];
+  };
+  {
+    double acc = 0.0;
+#pragma unroll
+    for (int q = 0; q < 6; q++) acc += cellval(C.vtx[q]);
+    out[cg_dof(C, 0, i, j, 0, 0)] = acc;
+  }
+  const bool valid[3] = {in_x, in_y, in_x && in_y};
+#pragma unroll
+  for (int t3 = 0; t3 < 3; t3++) {
+    if (!valid[t3]) continue;
+    for (int t = 0; t < C.p - 1; t++) out[cg_dof(C, 1 + t3, i, j, t, 0)] = cellval(C.edg[t3][t][0]) + cellval(C.edg[t3][t][1]);
+  }
+  if (in_x && in_y) {
+    for (int s = 0; s < 2; s++)
+      for (int q = 0; q < C.nint; q++) out[cg_dof(C, 4, i, j, q, s)] = y[(long)C.intr[s][q] * g.Nc + cidx(g, s, j, i)];
+  }
+}
+
+// Passive tracer transport (common.py:110-129), tendency in the orthonormal modal basis of DG_k (mass = identity):
+//   out_i = int_K q (grad chi_i . u + chi_i div u) - sum_{interior e} int_e chi_i (un_K q_K - un_K' q_K'),
+//   un_K = (u.n_K + |u.n_K|)/2 (outflow), un_K' = (|u.n_K| - u.n_K)/2 (inflow); u continuous, so taken from this cell.
+// The pressure / tracer modes are the first NP velocity modes (hierarchical Dubiner basis, same scaling), so the
+// tabulations of the advection operator serve both.  Cell rule exact to 3k+2, edge rule ceil((3k+4)/2) Gauss points.
+template <int K>
+__global__ __launch_bounds__(128) void k_tracer_adv(Geo g, DevTables T, const double* __restrict__ q, const double* __restrict__ u,
+                                                     double* __restrict__ out) {
+  constexpr int NU = Dim<K>::NU, NP = Dim<K>::NP;
+  HDG_CELL_PROLOGUE
+  double qc[NP], uc[2 * NU], F[NP];
+  load_cell<NP>(q, g.Nc, c, qc);
+  load_vel<NU>(u, g.Nc, c, uc);
+#pragma unroll
+  for (int r = 0; r < NP; r++) F[r] = 0.0;
+  {
+    const double* __restrict__ Phi = T.cPhi[s];
+    const double* __restrict__ Gx = T.cGx[s];
+    const double* __restrict__ Gy = T.cGy[s];
+#pragma unroll 1
+    for (int p = 0; p < T.nqc; p++) {
+      double qq = 0, ux = 0, uy = 0, dv = 0;
+#pragma unroll
+      for (int m = 0; m < NU; m++) {
+        const double ph = Phi[p * NU + m];
+        ux = fma(ph, uc[m], ux);
+        uy = fma(ph, uc[NU + m], uy);
+        dv = fma(Gx[p * NU + m], uc[m], fma(Gy[p * NU + m], uc[NU + m], dv));
+        if (m < NP) qq = fma(ph, qc[m], qq);
+      }
+      const double w = T.cw[p] * qq;
+#pragma unroll
+      for (int r = 0; r < NP; r++) F[r] = fma(w, fma(Gx[p * NU + r], ux, fma(Gy[p * NU + r], uy, Phi[p * NU + r] * dv)), F[r]);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 3; e++) {
+    long cn;
+    if (!nbr(s, e, i, j, g, cn)) continue;
+    double qn[NP];
+    load_cell<NP>(q, g.Nc, cn, qn);
+    const double* __restrict__ Po = T.ePhi[s][e];
+    const double* __restrict__ Pn = T.ePhi[1 - s][e];
+    const double nxo = T.sig[s][e] * T.enx[e], nyo = T.sig[s][e] * T.eny[e];
+#pragma unroll 1
+    for (int p = 0; p < T.nqe; p++) {
+      double un = 0, qk = 0, qm = 0;
+#pragma unroll
+      for (int m = 0; m < NU; m++) {
+        const double po = Po[p * NU + m];
+        un = fma(po, fma(nxo, uc[m], nyo * uc[NU + m]), un);
+        if (m < NP) { qk = fma(po, qc[m], qk); qm = fma(Pn[p * NU + m], qn[m], qm); }
+      }
+      const double a = fabs(un);
+      const double flux = T.ew[e][p] * (0.5 * (un + a) * qk - 0.5 * (a - un) * qm);
+#pragma unroll
+      for (int r = 0; r < NP; r++) F[r] = fma(-Po[p * NU + r], flux, F[r]);
+    }
+  }
+  store_cell<NP>(out, g.Nc, c, F);
+}
+
+}  // namespace hdg

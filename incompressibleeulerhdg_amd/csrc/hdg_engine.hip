@@ -29,6 +29,7 @@
 #include "../../include/hdg_mi355x.h"
 #include "hdg_comm.hpp"
 #include "hdg_kernels.hpp"
+#include "hdg_cg.hpp"
 #include "hdg_tables.hpp"
 
 namespace hdg {
@@ -1678,6 +1679,7 @@ struct Engine {
   void step() {
     Timed tm_(*this, T_STEP);
     begin_step();
+    tracer_begin_step();
     for (int i = 1; i < s; i++) {
       { Timed tb_(*this, T_BDM); bdm(stQ[i - 1], Qstar[i - 1]); }
       if (cfg.use_projection) {
@@ -1691,15 +1693,25 @@ struct Engine {
         unsplit_solve(i);
       }
       shift(stP[i], stL[i]);
+      tracer_stage(i);
     }
     pressure_solve(HDG_KEY_FINAL_STAGE);
     pressure_solve(HDG_KEY_PRESSURE_RECONSTRUCTION);
     finish_step();
+    tracer_finish_step();
   }
   // hdg_implicit.py:92-190 with use_projection_method=True.  Uses stage slot 0 for Q, slot 0 forcing.
   void implicit_step(int* its_t, int* its_p) {
     Timed tm_(*this, T_STEP);
     const double dtt = cfg.dt;
+    if (tracer_on) {  // hdg_implicit.py:93-96: b_tracer is built from the fields at the START of the step
+      cg_project(curQ, uproj);
+      tracer_adv(q_cur, uproj, q_t);
+    }
+    struct TracerEnd {  // hdg_implicit.py:192-193, on every return path of this function
+      Engine& E; double dtt;
+      ~TracerEnd() { if (E.tracer_on) E.axpby(E.NPv, dtt, E.q_t, 1.0, E.q_cur); }
+    } tracer_end_{*this, dtt};
     ensure_dinv(0, dtt);
     { Timed tb_(*this, T_BDM); bdm(curQ, Qstar[0]); }             // hdg_implicit.py:98
     if (!cfg.use_projection) {
@@ -1741,6 +1753,250 @@ struct Engine {
     shift(curP, curL);                                           // hdg_implicit.py:189-190
     if (its_t) *its_t = it1;
     if (its_p) *its_p = it2;
+  }
+
+
+  // ================================================================== continuous space CG_{k+1}, tracer, vorticity
+  // (hdg_cg.hpp; reference: common.py:110-129, hdg_imex.py:415-448,560,622-623,638-639, hdg_implicit.py:93-96,192-193,
+  //  callbacks.py:43-69).  Built on first use; single rank only.
+  CgTabs cgt;
+  bool cg_ready = false;
+  const double *cg_Mloc = nullptr, *cg_Wx[2] = {nullptr, nullptr}, *cg_Wy[2] = {nullptr, nullptr}, *cg_Eb = nullptr;
+  double *cg_y = nullptr, *cg_b = nullptr, *cg_x = nullptr, *cg_rr = nullptr, *cg_zz = nullptr, *cg_pp = nullptr, *cg_Ap2 = nullptr,
+         *cg_dinv = nullptr, *uproj = nullptr;
+  int cg_its_last = 0;
+  void cg_setup() {
+    if (cg_ready) return;
+    if (comm->size > 1) throw std::string("the continuous space (tracer, vorticity) is implemented for a single rank");
+    const int p = K + 1;
+    std::vector<real> xi, eta;
+    triangleNodes(p, cfg.equispaced_nodes, xi, eta);
+    if ((int)xi.size() != NU) throw std::string("node count mismatch");
+    std::memset(&cgt, 0, sizeof(cgt));
+    cgt.p = p; cgt.nint = (p - 1) * (p - 2) / 2; cgt.nx = g.nx; cgt.ny = g.ny;
+    const long nvt = (long)(g.nx + 1) * (g.ny + 1);
+    cgt.baseH = nvt;
+    cgt.baseV = cgt.baseH + (long)g.nx * (g.ny + 1) * (p - 1);
+    cgt.baseD = cgt.baseV + (long)(g.nx + 1) * g.ny * (p - 1);
+    cgt.baseI = cgt.baseD + (long)g.nx * g.ny * (p - 1);
+    cgt.ncg = cgt.baseI + 2L * g.nx * g.ny * cgt.nint;
+    // forward table from the lattice index (a, b) of each node (order: for b: for a), checked against coordinates below
+    int nv = 0, ne_cnt[3][4] = {{0}}, ni[2] = {0, 0};
+    for (int sh = 0; sh < 2; sh++) {
+      int n = 0;
+      for (int b = 0; b <= p; b++)
+        for (int a = 0; a <= p - b; a++, n++) {
+          const int c = p - a - b;
+          short* f = cgt.fwd[sh][n];
+          auto set = [&](int ty, int di, int dj, int t) { f[0] = (short)ty; f[1] = (short)di; f[2] = (short)dj; f[3] = (short)t; };
+          if (a == 0 && b == 0) sh == 0 ? set(0, 0, 0, 0) : set(0, 1, 1, 0);
+          else if (a == p) sh == 0 ? set(0, 1, 0, 0) : set(0, 0, 1, 0);
+          else if (b == p) sh == 0 ? set(0, 0, 1, 0) : set(0, 1, 0, 0);
+          else if (b == 0) sh == 0 ? set(1, 0, 0, a - 1) : set(1, 0, 1, p - a - 1);
+          else if (a == 0) sh == 0 ? set(2, 0, 0, b - 1) : set(2, 1, 0, p - b - 1);
+          else if (c == 0) sh == 0 ? set(3, 0, 0, b - 1) : set(3, 0, 0, a - 1);
+          else { set(4, 0, 0, ni[sh]); cgt.intr[sh][ni[sh]++] = (short)n; }
+          // inverse tables: the entity at corner (i + di, j + dj) receives cell (sh, i, j) node n
+          if (f[0] == 0) { short* v = cgt.vtx[nv++]; v[0] = (short)sh; v[1] = (short)-f[1]; v[2] = (short)-f[2]; v[3] = (short)n; }
+          else if (f[0] <= 3) {
+            int& k2 = ne_cnt[f[0] - 1][f[3]];
+            short* v = cgt.edg[f[0] - 1][f[3]][k2++];
+            v[0] = (short)sh; v[1] = (short)-f[1]; v[2] = (short)-f[2]; v[3] = (short)n;
+          }
+        }
+    }
+    if (nv != 6 || ni[0] != cgt.nint || ni[1] != cgt.nint) throw std::string("continuous-space tables inconsistent");
+    // cross-check: physical position of every local node of cell (sh, 0, 0) on the unit-h square against its entity
+    {
+      std::vector<real> gl = gllPoints(p);
+      if (cfg.equispaced_nodes) { gl.clear(); for (int q = 0; q <= p; q++) gl.push_back((real)q / p); }
+      for (int sh = 0; sh < 2; sh++)
+        for (int n = 0; n < NU; n++) {
+          const short* f = cgt.fwd[sh][n];
+          const double x = sh == 0 ? (double)xi[n] : 1.0 - (double)xi[n], y = sh == 0 ? (double)eta[n] : 1.0 - (double)eta[n];
+          double ex, ey;
+          const double t = f[0] >= 1 && f[0] <= 3 ? (double)gl[f[3] + 1] : 0.0;
+          if (f[0] == 0) { ex = f[1]; ey = f[2]; }
+          else if (f[0] == 1) { ex = f[1] + t; ey = f[2]; }
+          else if (f[0] == 2) { ex = f[1]; ey = f[2] + t; }
+          else if (f[0] == 3) { ex = f[1] + 1.0 - t; ey = f[2] + t; }
+          else continue;
+          if (std::fabs(x - ex) > 1e-12 || std::fabs(y - ey) > 1e-12) throw std::string("continuous-space node classification failed");
+        }
+    }
+    // local matrices: nodal mass Vinv^T Vinv; curl blocks W[m][l] = int d psi_m psi_l; boundary edge mass
+    dvec Ml((size_t)NU * NU, 0.0);
+    for (int a = 0; a < NU; a++)
+      for (int b = 0; b < NU; b++) {
+        long double acc = 0;
+        for (int m = 0; m < NU; m++) acc += (long double)tab->Vuinv[m * NU + a] * tab->Vuinv[m * NU + b];
+        Ml[(size_t)a * NU + b] = (double)acc;
+      }
+    cg_Mloc = upload(Ml);
+    dvec Eb((size_t)2 * 3 * NU * NU, 0.0);
+    for (int sh = 0; sh < 2; sh++) {
+      dvec Wx((size_t)NU * NU, 0.0), Wy((size_t)NU * NU, 0.0);
+      for (int q = 0; q < tab->nqc; q++)
+        for (int m = 0; m < NU; m++)
+          for (int l = 0; l < NU; l++) {
+            Wx[(size_t)m * NU + l] += tab->cw[q] * tab->cGx[sh][q * NU + m] * tab->cPhi[sh][q * NU + l];
+            Wy[(size_t)m * NU + l] += tab->cw[q] * tab->cGy[sh][q * NU + m] * tab->cPhi[sh][q * NU + l];
+          }
+      cg_Wx[sh] = upload(Wx); cg_Wy[sh] = upload(Wy);
+      for (int e = 0; e < 3; e++)
+        for (int q = 0; q < tab->nqe; q++)
+          for (int m = 0; m < NU; m++)
+            for (int l = 0; l < NU; l++)
+              Eb[(((size_t)sh * 3 + e) * NU + m) * NU + l] += tab->ew[e][q] * tab->ePhi[sh][e][q * NU + m] * tab->ePhi[sh][e][q * NU + l];
+    }
+    cg_Eb = upload(Eb);
+    cg_y = dalloc((long)NU * g.Nc);
+    for (double** v : {&cg_b, &cg_x, &cg_rr, &cg_zz, &cg_pp, &cg_Ap2, &cg_dinv}) *v = dalloc(cgt.ncg);
+    uproj = dalloc(NQ);
+    cg_ready = true;
+    // Jacobi preconditioner: diagonal of the mass matrix = M applied dof by dof is too dear; use the row sums of |M| instead?
+    // The diagonal itself: gather of diag(Mloc): y_K[n] = Mloc[n][n]
+    {
+      dvec dg((size_t)NU * g.Nc, 0.0);
+      for (int n = 0; n < NU; n++)
+        for (long cc = 0; cc < g.Nc; cc++) dg[(size_t)n * g.Nc + cc] = Ml[(size_t)n * NU + n];
+      HIPCHECK(hipMemcpyAsync(cg_y, dg.data(), sizeof(double) * dg.size(), hipMemcpyHostToDevice, stream));
+      HDG_DISPATCH(k_cg_gather<KK><<<corner_grid_all(), bs(), 0, stream>>>(g_all, cgt, cg_y, cg_dinv));
+      HIPCHECK(hipStreamSynchronize(stream));
+    }
+  }
+  void cg_mass(const double* c_in, double* out) {  // out = M_CG c_in
+    HDG_DISPATCH(k_cg_cell<KK, 0><<<cell_grid(), bs(), 0, stream>>>(g, cgt, dt, cg_Mloc, dt.Vuinv, nullptr, nullptr, nullptr, nullptr,
+                                                                     nullptr, c_in, nullptr, 0, cg_y));
+    HDG_DISPATCH(k_cg_gather<KK><<<corner_grid_all(), bs(), 0, stream>>>(g_all, cgt, cg_y, out));
+  }
+  double dot_plain(long n, const double* a, const double* b) {
+    VecList<4> vl{};
+    vl.p[0] = b;
+    const int nb = std::min(dot_blocks, vec_blocks(n));
+    k_multidot<4, false><<<nb, HDG_DOT_BLOCK, 0, stream>>>(n, a, vl, 1, d_part, RowMask{0, 1, 0, 0}, 0);
+    k_reduce_parts<<<1, 256, 0, stream>>>(nb, 1, d_part, d_res);
+    HIPCHECK(hipMemcpyAsync(h_res, d_res, sizeof(double), hipMemcpyDeviceToHost, stream));
+    HIPCHECK(hipStreamSynchronize(stream));
+    return h_res[0];
+  }
+  // solve M_CG x = b (b in cg_b) by Jacobi-preconditioned CG to rtol 1e-13 on the preconditioned residual; result in cg_x
+  void cg_solve() {
+    const long n = cgt.ncg;
+    zero(cg_x, n);
+    copy(cg_rr, cg_b, n);
+    auto precond = [&]() {  // z = r / diag
+      k_pointwise_div<<<vec_blocks(n), 256, 0, stream>>>(n, cg_rr, cg_dinv, cg_zz);
+    };
+    precond();
+    double rz = dot_plain(n, cg_rr, cg_zz);
+    const double rz0 = rz;
+    if (!(rz0 > 0.0)) { cg_its_last = 0; return; }
+    copy(cg_pp, cg_zz, n);
+    for (int it = 1; it <= 500; it++) {
+      cg_mass(cg_pp, cg_Ap2);
+      const double alpha = rz / dot_plain(n, cg_pp, cg_Ap2);
+      axpby(n, alpha, cg_pp, 1.0, cg_x);
+      axpby(n, -alpha, cg_Ap2, 1.0, cg_rr);
+      precond();
+      const double rzn = dot_plain(n, cg_rr, cg_zz);
+      cg_its_last = it;
+      if (rzn <= 1e-26 * rz0) return;
+      axpby(n, 1.0, cg_zz, rzn / rz, cg_pp);
+      rz = rzn;
+    }
+    throw NotConverged{"continuous-space mass solve did not converge"};
+  }
+  // L2 projection of a broken velocity onto [CG_{k+1}]^2 (common.py:119-122); result as a broken modal vector
+  void cg_project(const double* vel_in, double* vel_out) {
+    cg_setup();
+    for (int d = 0; d < 2; d++) {
+      HDG_DISPATCH(k_cg_cell<KK, 1><<<cell_grid(), bs(), 0, stream>>>(g, cgt, dt, cg_Mloc, dt.Vuinv, nullptr, nullptr, nullptr, nullptr,
+                                                                       nullptr, nullptr, const_cast<double*>(vel_in), d, cg_y));
+      HDG_DISPATCH(k_cg_gather<KK><<<corner_grid_all(), bs(), 0, stream>>>(g_all, cgt, cg_y, cg_b));
+      cg_solve();
+      HDG_DISPATCH(k_cg_cell<KK, 2><<<cell_grid(), bs(), 0, stream>>>(g, cgt, dt, cg_Mloc, dt.Vuinv, nullptr, nullptr, nullptr, nullptr,
+                                                                       nullptr, cg_x, vel_out, d, nullptr));
+    }
+  }
+  // vorticity of a broken velocity in CG_{k+1} (callbacks.py:43-69); result in cg_x (ncg values)
+  void vorticity(const double* vel_in) {
+    cg_setup();
+    HDG_DISPATCH(k_cg_cell<KK, 3><<<cell_grid(), bs(), 0, stream>>>(g, cgt, dt, cg_Mloc, dt.Vuinv, cg_Wx[0], cg_Wy[0], cg_Wx[1], cg_Wy[1],
+                                                                     cg_Eb, nullptr, const_cast<double*>(vel_in), 0, cg_y));
+    HDG_DISPATCH(k_cg_gather<KK><<<corner_grid_all(), bs(), 0, stream>>>(g_all, cgt, cg_y, cg_b));
+    cg_solve();
+  }
+  void cg_coordinates(double* xy) const {  // physical position of every continuous dof
+    const int p = cgt.p;
+    std::vector<real> gl = cfg.equispaced_nodes ? std::vector<real>() : gllPoints(p);
+    if (cfg.equispaced_nodes) for (int q = 0; q <= p; q++) gl.push_back((real)q / p);
+    std::vector<real> xi, eta;
+    triangleNodes(p, cfg.equispaced_nodes, xi, eta);
+    const double h = g.h;
+    auto put = [&](long id, double x, double y) { xy[2 * id] = x; xy[2 * id + 1] = y; };
+    for (int j = 0; j <= g.ny; j++)
+      for (int i = 0; i <= g.nx; i++) {
+        put((long)j * (g.nx + 1) + i, i * h, j * h);
+        for (int t = 0; t < p - 1; t++) {
+          const double tt = (double)gl[t + 1];
+          if (i < g.nx) put(cgt.baseH + ((long)j * g.nx + i) * (p - 1) + t, (i + tt) * h, j * h);
+          if (j < g.ny) put(cgt.baseV + ((long)j * (g.nx + 1) + i) * (p - 1) + t, i * h, (j + tt) * h);
+          if (i < g.nx && j < g.ny) put(cgt.baseD + ((long)j * g.nx + i) * (p - 1) + t, (i + 1 - tt) * h, (j + tt) * h);
+        }
+        if (i < g.nx && j < g.ny)
+          for (int sh = 0; sh < 2; sh++)
+            for (int q = 0; q < cgt.nint; q++) {
+              const int n = cgt.intr[sh][q];
+              const double x = sh == 0 ? (double)xi[n] : 1.0 - (double)xi[n], y = sh == 0 ? (double)eta[n] : 1.0 - (double)eta[n];
+              put(cgt.baseI + (((long)j * g.nx + i) * 2 + sh) * cgt.nint + q, (i + x) * h, (j + y) * h);
+            }
+      }
+  }
+
+  // ------------------------------------------------------------------ passive tracer (explicit DG transport)
+  bool tracer_on = false;
+  double *q_cur = nullptr, *q_fin = nullptr, *q_t = nullptr;
+  std::vector<double*> q_st;
+  void tracer_alloc() {
+    if (q_cur) return;
+    q_cur = dalloc(NPv); q_fin = dalloc(NPv); q_t = dalloc(NPv);
+    for (int i = 0; i < s; i++) q_st.push_back(dalloc(NPv));
+  }
+  // out = M^-1 T(.; q, u) for a continuous velocity u given as a broken modal vector
+  void tracer_adv(const double* q, const double* u, double* out) {
+    halo_P(q);
+    HDG_DISPATCH(k_tracer_adv<KK><<<cell_grid(), bs(), 0, stream>>>(g, dt, q, u, out));
+  }
+  // hdg_imex.py:560 and the i = 0 term of _tracer_final_residual
+  void tracer_begin_step() {
+    if (!tracer_on) return;
+    copy(q_st[0], q_cur, NPv);
+    copy(q_fin, q_cur, NPv);
+    if (cfg.b_expl[0] != 0.0) {
+      cg_project(stQ[0], uproj);
+      tracer_adv(q_st[0], uproj, q_t);
+      axpby(NPv, cfg.dt * cfg.b_expl[0], q_t, 1.0, q_fin);
+    }
+  }
+  // hdg_imex.py:622-623: q_i = q_0 + dt sum_{j<i} a_expl[i,j] T(q_j, P(Q_i)); plus the i-th term of the final residual
+  void tracer_stage(int i) {
+    if (!tracer_on) return;
+    if (i < 1 || i >= s) throw std::string("stage out of range");
+    cg_project(stQ[i], uproj);
+    copy(q_st[i], q_st[0], NPv);
+    for (int j = 0; j < i; j++)
+      if (cfg.a_expl[i * s + j] != 0.0) {
+        tracer_adv(q_st[j], uproj, q_t);
+        axpby(NPv, cfg.dt * cfg.a_expl[i * s + j], q_t, 1.0, q_st[i]);
+      }
+    if (cfg.b_expl[i] != 0.0) {
+      tracer_adv(q_st[i], uproj, q_t);
+      axpby(NPv, cfg.dt * cfg.b_expl[i], q_t, 1.0, q_fin);
+    }
+  }
+  void tracer_finish_step() {  // hdg_imex.py:638-639
+    if (tracer_on) copy(q_cur, q_fin, NPv);
   }
 
   // ------------------------------------------------------------------ host <-> device fields
@@ -2099,6 +2355,96 @@ int hdg_get_timers(hdg_handle* h, double* total_ms, double* sumsq_ms, long* ncal
     if (ncalls) ncalls[i] = E.tm_calls[i];
     if (reset) { E.tm_total[i] = 0; E.tm_sumsq[i] = 0; E.tm_calls[i] = 0; }
   }
+  HDG_API_END(h)
+}
+// ---- passive tracer and continuous-space diagnostics
+int hdg_set_tracer(hdg_handle* h, const double* q) {
+  HDG_API_BEGIN(h)
+  if (!q) { E.tracer_on = false; }
+  else {
+    E.cg_setup();
+    E.tracer_alloc();
+    E.put_P(q, E.q_cur);
+    E.tracer_on = true;
+  }
+  HDG_API_END(h)
+}
+int hdg_get_tracer(hdg_handle* h, double* q) {
+  HDG_API_BEGIN(h)
+  if (!E.tracer_on || !q) throw std::string("no tracer field");
+  E.get_P(E.q_cur, q);
+  HDG_API_END(h)
+}
+int hdg_tracer_begin_step(hdg_handle* h) {
+  HDG_API_BEGIN(h)
+  E.tracer_begin_step();
+  HDG_API_END(h)
+}
+int hdg_tracer_stage(hdg_handle* h, int stage) {
+  HDG_API_BEGIN(h)
+  E.tracer_stage(stage);
+  HDG_API_END(h)
+}
+int hdg_tracer_finish_step(hdg_handle* h) {
+  HDG_API_BEGIN(h)
+  E.tracer_finish_step();
+  HDG_API_END(h)
+}
+int hdg_cg_size(hdg_handle* h, long* n_cg) {
+  HDG_API_BEGIN(h)
+  if (!n_cg) throw std::string("null argument");
+  E.cg_setup();
+  *n_cg = E.cgt.ncg;
+  HDG_API_END(h)
+}
+int hdg_cg_coordinates(hdg_handle* h, double* xy) {
+  HDG_API_BEGIN(h)
+  if (!xy) throw std::string("null argument");
+  E.cg_setup();
+  E.cg_coordinates(xy);
+  HDG_API_END(h)
+}
+int hdg_cg_project_nodal(hdg_handle* h, const double* Qin, double* Qout) {
+  HDG_API_BEGIN(h)
+  if (!Qin || !Qout) throw std::string("null argument");
+  E.put_Q(Qin, E.wQ1);
+  E.cg_project(E.wQ1, E.wQ2);
+  E.get_Q(E.wQ2, Qout);
+  HDG_API_END(h)
+}
+int hdg_vorticity(hdg_handle* h, const double* Q, double* omega) {
+  HDG_API_BEGIN(h)
+  if (!omega) throw std::string("null argument");
+  const double* src = E.curQ;
+  if (Q) { E.put_Q(Q, E.wQ1); src = E.wQ1; }
+  E.vorticity(src);
+  if (hipMemcpyAsync(omega, E.cg_x, sizeof(double) * E.cgt.ncg, hipMemcpyDeviceToHost, E.stream) != hipSuccess)
+    throw hdg::HipError{"hipMemcpyAsync failed"};
+  HDG_API_END(h)
+}
+int hdg_cg_to_broken(hdg_handle* h, const double* cg_values, double* broken) {
+  HDG_API_BEGIN(h)
+  if (!cg_values || !broken) throw std::string("null argument");
+  E.cg_setup();
+  if (hipMemcpyAsync(E.cg_b, cg_values, sizeof(double) * E.cgt.ncg, hipMemcpyHostToDevice, E.stream) != hipSuccess)
+    throw hdg::HipError{"hipMemcpyAsync failed"};
+  const int K = E.K;
+  HDG_DISPATCH(hdg::k_cg_to_broken<KK><<<E.cell_grid(), E.bs(), 0, E.stream>>>(E.g, E.cgt, E.cg_b, E.hQ_dev));
+  if (hipMemcpyAsync(broken, E.hQ_dev, sizeof(double) * E.NQb / 2, hipMemcpyDeviceToHost, E.stream) != hipSuccess)
+    throw hdg::HipError{"hipMemcpyAsync failed"};
+  HDG_API_END(h)
+}
+int hdg_apply_tracer_advection(hdg_handle* h, const double* q, const double* u, int project, double* out) {
+  HDG_API_BEGIN(h)
+  if (!q || !u || !out) throw std::string("null argument");
+  E.cg_setup();
+  E.tracer_alloc();
+  E.put_Q(u, E.wQ1);
+  const double* vel = E.wQ1;
+  if (project) { E.cg_project(E.wQ1, E.uproj); vel = E.uproj; }
+  E.put_P(q, E.wP1);
+  E.tracer_adv(E.wP1, vel, E.q_t);
+  E.get_P(E.q_t, out);
   HDG_API_END(h)
 }
 int hdg_apply_advection(hdg_handle* h, const double* Qstar, const double* x, double gamma, double* y) {

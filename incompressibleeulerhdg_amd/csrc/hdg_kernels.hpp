@@ -2032,6 +2032,11 @@ __global__ void k_p1_prolong_add(int nc, const double* __restrict__ xc, double* 
   else v = 0.5 * (xc[J * sc + I + 1] + xc[(J + 1) * sc + I]);
   xf[j * (nf + 1) + i] += v;
 }
+// z = r / d (Jacobi preconditioner of the continuous-space mass matrix)
+__global__ void k_pointwise_div(long N, const double* __restrict__ r, const double* __restrict__ d, double* __restrict__ z) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < N; idx += stride) z[idx] = r[idx] / d[idx];
+}
 __global__ void k_fill(long N, double* __restrict__ x, double v) {
   const long stride = (long)gridDim.x * blockDim.x;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < N; idx += stride) x[idx] = v;

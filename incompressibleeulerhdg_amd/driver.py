@@ -2,8 +2,9 @@
 
     python -m incompressibleeulerhdg_amd.driver --nx 64 --degree 2 --use_projection_method
 
-Out of scope here: ``--animation``, ``--tracer_advection``, the
-``kelvinhelmholtz`` / ``shear`` problems and the ``conforming`` / ``dg`` discretisations.  The final fields are
+Out of scope here: the ``kelvinhelmholtz`` / ``shear`` problems (unstructured / periodic
+meshes) and the ``conforming`` / ``dg`` discretisations.  ``--animation`` (evolution.pvd with the CG vorticity,
+callbacks.py:30-85) and ``--tracer_advection`` (driver.py:340-344) are supported.  The final fields are
 written to ``solution.pvd`` (``--output``) like the reference does (driver.py:356-385).
 """
 import argparse
@@ -12,6 +13,7 @@ import time
 
 import numpy as np
 
+from .auxilliary.callbacks import AnimationCallback
 from .auxilliary.logging import log_summary
 from .mesh import Function, UnitSquareMesh
 from .model_problems import TaylorGreen
@@ -52,8 +54,9 @@ def build_parser():
     parser.add_argument("--forcing", choices=["exponential", "constant"], type=str, default="exponential", help="forcing")
     parser.add_argument("--test_pressure_solver", action="store_true", default=False, help="carry out a single solve with the pressure solver for testing")
     parser.add_argument("--warmup", action="store_true", default=False, help="only perform one timestep")
-    parser.add_argument("--animation", action="store_true", default=False, help="(out of scope)")
-    parser.add_argument("--tracer_advection", action="store_true", default=False, help="(out of scope)")
+    parser.add_argument("--animation", action="store_true", default=False,
+                        help="save velocity and pressure fields at the end of each timestep as an animation")
+    parser.add_argument("--tracer_advection", action="store_true", default=False, help="advect tracer field")
     # additions of the build
     parser.add_argument("--fused", action="store_true", default=False, help="run each timestep as one device-resident call")
     parser.add_argument("--output", type=str, default="solution.pvd",
@@ -68,17 +71,16 @@ def main(argv=None):
         raise RuntimeError(f"problem '{args.problem}' is out of scope of the MI355X hot path")
     if args.discretisation != "hdg":
         raise RuntimeError(f"discretisation '{args.discretisation}' is out of scope of the MI355X hot path")
-    if args.animation or args.tracer_advection:
-        raise RuntimeError("--animation / --tracer_advection are out of scope of the MI355X hot path")
+    callbacks = [AnimationCallback("evolution.pvd")] if args.animation else None  # driver.py:187
     mesh = UnitSquareMesh(args.nx, args.nx, quadrilateral=False)  # driver.py:181
     if args.timestepper == "implicit":
         timestepper = IncompressibleEulerHDGImplicit(  # driver.py:220-228 (passes n_richardson: SURVEY C-1)
             mesh, args.degree, args.dt, flux=args.flux, use_projection_method=args.use_projection_method,
-            n_richardson=args.richardson, callbacks=None, device=args.device)
+            n_richardson=args.richardson, callbacks=callbacks, device=args.device)
     elif args.timestepper in TIMESTEPPERS:
         timestepper = TIMESTEPPERS[args.timestepper](
             mesh, args.degree, args.dt, flux=args.flux, use_projection_method=args.use_projection_method,
-            n_richardson=args.richardson, callbacks=None, device=args.device)
+            n_richardson=args.richardson, callbacks=callbacks, device=args.device)
     else:
         raise RuntimeError(f"Invalid timestepping method for HDG discretisation: '{args.timestepper}'")
 
@@ -131,8 +133,10 @@ def main(argv=None):
         print()
     model_problem = TaylorGreen(timestepper._V_Q, timestepper._V_p, args.forcing, args.kappa)
     Q_0, p_0 = model_problem.initial_condition()
+    # driver.py:340-344
+    q_0 = (lambda x, y: np.sin(2 * np.pi * x) * np.sin(2 * np.pi * y)) if args.tracer_advection else None
     kw = {"fused": True} if (args.fused and args.timestepper != "implicit") else {}
-    Q, p = timestepper.solve(Q_0, p_0, None, model_problem.f_rhs(), args.tfinal, warmup=args.warmup, **kw)
+    Q, p = timestepper.solve(Q_0, p_0, q_0, model_problem.f_rhs(), args.tfinal, warmup=args.warmup, **kw)
     log_summary()
     if not args.warmup:
         Q.rename("velocity")

@@ -40,7 +40,9 @@ class IncompressibleEuler(ABC):
         k = self.degree
         self._V_Q = FunctionSpace(self._mesh, "DG", k + 1, xq, value_size=2)
         self._V_p = FunctionSpace(self._mesh, "DG", k, xp)
-        self._V_q = self._V_p
+        self._V_q = self._V_p  # tracer space DG_k (hdg_imex.py:68)
+        for V in (self._V_Q, self._V_p):
+            V._engine = self._engine  # device operations on a Function (vorticity callback)
         self._V_trace = ("DGT", k, self._engine.n_edges * self._engine.n_l)
         self._V = (self._V_Q, self._V_p, self._V_trace)
         return self._engine
@@ -79,6 +81,21 @@ class IncompressibleEuler(ABC):
         zero normal component on the boundary)."""
         out = self._engine.project_bdm_nodal(self._as_nodal_velocity(Q))
         return Function(self._V_Q, out, "Q_star")
+
+    def _init_tracer(self, q_initial):
+        """q_initial (expression / array / None, driver.py:340-344) -> the engine's tracer state; returns whether a
+        tracer is advected."""
+        if q_initial is None or q_initial is False:
+            self._engine.set_tracer(None)
+            self.q_tracer = None
+            return False
+        self._engine.set_tracer(self._as_nodal_pressure(q_initial))
+        self.q_tracer = Function(self._V_q, self._engine.get_tracer(), "tracer")
+        return True
+
+    def _tracer_function(self):
+        self.q_tracer = Function(self._V_q, self._engine.get_tracer(), "tracer")
+        return self.q_tracer
 
     @abstractmethod
     def solve(self, Q_initial, p_initial, q_initial, f_rhs, T_final, warmup=False):

@@ -128,9 +128,8 @@ class IncompressibleEulerHDGIMEX(IncompressibleEuler):
         ``fused=True`` runs each step as one device-resident ``hdg_step`` call instead of the
         per-solve calls that mirror the reference's loop (identical results, no per-solve timers).
         """
-        if q_initial:
-            raise NotImplementedError("passive tracer advection is out of scope (SURVEY.md section 2.1)")
         eng = self._engine
+        tracer = self._init_tracer(q_initial)  # hdg_imex.py:523-529
         s = self.nstages
         nt = self.get_timesteps(T_final, warmup)
         self._forcing_profile = None
@@ -144,7 +143,7 @@ class IncompressibleEulerHDGIMEX(IncompressibleEuler):
         for callback in self.callbacks:
             callback.reset()
             Q, p, _ = eng.get_field(_lib.HDG_STATE_CURRENT, lam=False)
-            callback(Function(self._V_Q, Q, "Q"), Function(self._V_p, p, "p"), 0, q_tracer=None)
+            callback(Function(self._V_Q, Q, "Q"), Function(self._V_p, p, "p"), 0, q_tracer=self.q_tracer)
         for k in range(nt):
             with PerformanceLog("timestep"):
                 tn = k * self._dt
@@ -155,6 +154,8 @@ class IncompressibleEulerHDGIMEX(IncompressibleEuler):
                     eng.step()
                 else:
                     eng.begin_step()
+                    if tracer:
+                        eng.tracer_begin_step()  # self._q[0].assign(q_tracer), hdg_imex.py:560
                     for i in range(1, s):
                         with PerformanceLog("bdm_projection"):
                             eng.project_bdm(i - 1, i - 1)
@@ -171,15 +172,20 @@ class IncompressibleEulerHDGIMEX(IncompressibleEuler):
                                 its = eng.unsplit_solve(i)  # hdg_imex.py:600-620
                             self.niter_tentative.update(its)
                         self._shift_pressure(i)
+                        if tracer:
+                            eng.tracer_stage(i)  # hdg_imex.py:622-623
                     its = self.pressure_solve("final_stage")
                     self.niter_final_pressure.update(its)
                     its = self.pressure_solve("pressure_reconstruction")
                     self.niter_pressure_reconstruction.update(its)
                     eng.finish_step()
+                    if tracer:
+                        eng.tracer_finish_step()  # hdg_imex.py:638-639
             if self.callbacks:
                 Q, p, _ = eng.get_field(_lib.HDG_STATE_CURRENT, lam=False)
+                qt = self._tracer_function() if tracer else None
                 for callback in self.callbacks:
-                    callback(Function(self._V_Q, Q, "Q"), Function(self._V_p, p, "p"), tn + self._dt, q_tracer=None)
+                    callback(Function(self._V_Q, Q, "Q"), Function(self._V_p, p, "p"), tn + self._dt, q_tracer=qt)
         if fused:
             # per-solve breakdown of the fused steps from the engine's device-side timers (same labels as the
             # host timers of the per-solve path; "timestep" is already timed on the host)
@@ -199,6 +205,8 @@ class IncompressibleEulerHDGIMEX(IncompressibleEuler):
         print(f"  pressure reconstruction its : {self.niter_pressure_reconstruction.value:8.2f}")
         print()
         Q, p, _ = eng.get_field(_lib.HDG_STATE_CURRENT, lam=False)
+        if tracer:
+            self._tracer_function()  # the final tracer field: self.q_tracer (the reference returns (Q, p) only)
         return Function(self._V_Q, Q, "Q"), Function(self._V_p, p, "p")
 
 

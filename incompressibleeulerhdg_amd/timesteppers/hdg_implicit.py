@@ -33,16 +33,15 @@ class IncompressibleEulerHDGImplicit(IncompressibleEuler):
                             b_impl=[1], c_expl=[0])
 
     def solve(self, Q_initial, p_initial, q_initial, f_rhs, T_final, warmup=False):
-        if q_initial:
-            raise NotImplementedError("passive tracer advection is out of scope")
         eng = self._engine
+        tracer = self._init_tracer(q_initial)  # hdg_implicit.py:72-78
         nt = self.get_timesteps(T_final, warmup)
         eng.set_state(self._as_nodal_velocity(Q_initial), self._as_nodal_pressure(p_initial))
         profile = None
         for callback in self.callbacks:
             callback.reset()
             Q, p, _ = eng.get_field(_lib.HDG_STATE_CURRENT, lam=False)
-            callback(Function(self._V_Q, Q), Function(self._V_p, p), 0, q_tracer=None)
+            callback(Function(self._V_Q, Q), Function(self._V_p, p), 0, q_tracer=self.q_tracer)
         for k in range(nt):
             with PerformanceLog("timestep"):
                 t = k * self._dt  # forcing at the START of the step (hdg_implicit.py:100)
@@ -60,7 +59,10 @@ class IncompressibleEulerHDGImplicit(IncompressibleEuler):
                 self.niter_pressure.update(it_p)
             if self.callbacks:
                 Q, p, _ = eng.get_field(_lib.HDG_STATE_CURRENT, lam=False)
+                qt = self._tracer_function() if tracer else None
                 for callback in self.callbacks:
-                    callback(Function(self._V_Q, Q), Function(self._V_p, p), (k + 1) * self._dt, q_tracer=None)
+                    callback(Function(self._V_Q, Q), Function(self._V_p, p), (k + 1) * self._dt, q_tracer=qt)
         Q, p, _ = eng.get_field(_lib.HDG_STATE_CURRENT, lam=False)
+        if tracer:
+            self._tracer_function()
         return Function(self._V_Q, Q, "velocity"), Function(self._V_p, p, "pressure")
