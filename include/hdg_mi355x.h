@@ -78,6 +78,11 @@ typedef struct hdg_config {
   int unsplit_restart;
   int unsplit_maxit;
   int device;            /* HIP device ordinal */
+  /* mesh variants: periodic != 0 selects the doubly periodic square
+   * PeriodicSquareMesh(nx, nx, L) of driver.py:182-183 (no boundary edges, 3 nx ny edges, single rank); length = side
+   * of the square (0 means 1: UnitSquareMesh, driver.py:181) */
+  int periodic;
+  double length;
 } hdg_config;
 
 typedef struct hdg_handle hdg_handle;

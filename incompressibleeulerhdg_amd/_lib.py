@@ -66,6 +66,8 @@ class hdg_config(C.Structure):
         ("unsplit_restart", C.c_int),
         ("unsplit_maxit", C.c_int),
         ("device", C.c_int),
+        ("periodic", C.c_int),
+        ("length", C.c_double),
     ]
 
 
@@ -219,6 +221,8 @@ class Engine:
         cfg.unsplit_restart = int(kw.get("unsplit_restart", 30))
         cfg.unsplit_maxit = int(kw.get("unsplit_maxit", 600))
         cfg.device = int(kw.get("device", 0))
+        cfg.periodic = 1 if kw.get("periodic", False) else 0
+        cfg.length = float(kw.get("length", 1.0))
         self.cfg = cfg
         self.h = _h()
         self.rank, self.nranks = int(kw.get("rank", 0)), int(kw.get("nranks", 1))
@@ -242,7 +246,7 @@ class Engine:
         self.shape_l = (self.n_edges * self.n_l,)
         # dimension of the GLOBAL mixed state (Q, p, lambda) advanced per step
         nxg, nyg = cfg.nx, cfg.ny
-        self.n_total = 2 * nxg * nyg * (2 * self.n_u + self.n_p) + (3 * nxg * nyg + nxg + nyg) * self.n_l
+        self.n_total = 2 * nxg * nyg * (2 * self.n_u + self.n_p) + (3 * nxg * nyg + (0 if cfg.periodic else nxg + nyg)) * self.n_l
 
     def _ck(self, rc):
         if rc != 0:

@@ -65,6 +65,8 @@ struct Engine {
   long NQ, NPv, NLv;  // vector lengths incl. ghost rows: velocity, pressure, trace (padded)
   long NQb, NPb, NLb;  // lengths of the nodal arrays at the C boundary (this rank's strip, no ghosts)
   Comm* comm = nullptr;
+  bool periodic = false;  // doubly periodic square (hdg_config::periodic)
+  double Ldom = 1.0;      // side of the square
   Geo g_all;           // same strip, but corner kernels visit every local row 0..ny (conversions)
   double *hb_slo = nullptr, *hb_shi = nullptr, *hb_rlo = nullptr, *hb_rhi = nullptr;  // halo buffers
   double* mg_gather = nullptr;
@@ -241,17 +243,28 @@ struct Engine {
     g.ny = c.ny / comm->size;
     g.joff = comm->rank * g.ny;
     g.nyc = g.ny + (comm->rank == comm->size - 1 ? 1 : 0);
+    periodic = c.periodic != 0;
+    Ldom = c.length > 0 ? c.length : 1.0;
+    if (periodic && comm->size > 1) throw std::string("the periodic mesh is implemented for a single rank");
+    if (periodic && (c.nx % 2 != 0)) throw std::string("the periodic mesh needs an even nx (red-black coarse-grid sweeps)");
+    if (periodic) {
+      // y-periodicity without touching a kernel: the strip pretends to lie in the middle of a taller mesh (no physical
+      // boundary test in y fires, the top H row is a ghost copy of the bottom one like on a rank below another) and its
+      // ghost rows are filled from its own opposite side (halo_rows -> k_wrap_rows)
+      g.joff = g.ny; g.nyg = 3 * g.ny; g.nyc = g.ny;
+    }
+    g.px = periodic ? 1 : 0;
     g.P = ((c.nx + 1 + 15) / 16) * 16;
     g.G = (long)(g.ny + 2) * g.P;
     g.Nc = 2L * c.nx * (g.ny + 2);
-    g.h = 1.0 / c.nx;
+    g.h = Ldom / c.nx;
     g.nbx = (g.nx + bs() - 1) / bs();
     g.nbxc = (g.nx + 1 + bs() - 1) / bs();
     g.rows_xcd = (g.ny + 7) / 8;
     g.rows_xcdc = (g.nyc + 7) / 8;
     g.dbg_nonbr = std::getenv("HDG_DBG_NONBR") ? 1 : 0;
     g_all = g;
-    g_all.nyc = g.ny + 1;
+    g_all.nyc = g.ny + (periodic ? 0 : 1);
     g_all.rows_xcdc = (g_all.nyc + 7) / 8;
     NQ = 2L * NU * g.Nc; NPv = (long)NP * g.Nc; NLv = 3L * NL * g.G;
     // cell kernels address a vector with 32-bit byte offsets (buffer loads, hdg_kernels.hpp: CellBuf)
@@ -261,6 +274,7 @@ struct Engine {
     NQb = 2L * NU * 2L * g.nx * g.ny; NPb = (long)NP * 2L * g.nx * g.ny;
     NLb = n_edges() * NL;
     tab = new Tables(K, g.h, c.tau, c.alpha_penalty, c.equispaced_nodes);
+    if (periodic) cfg.trace_precond = cfg.trace_precond ? 1 : 0;
     build_dev_tables();
     alloc_state();
     setup_trace_solver();
@@ -366,6 +380,10 @@ struct Engine {
   bool halo_on = true;  // switched off while timing bare kernel launches (hdg_time_kernel is not collective)
   long n_halo[3] = {0, 0, 0}, n_reduce = 0, n_gather = 0;  // communication census (HDG_DEBUG, printed at destruction)
   void halo_rows(double* v, long plane_stride, int row_len, int nplanes, int kind) {
+    if (periodic && halo_on) {  // ghost rows = the owned rows of the opposite side
+      k_wrap_rows<<<std::min(vec_blocks((long)nplanes * row_len), 512), 256, 0, stream>>>(v, plane_stride, row_len, nplanes, g.ny);
+      return;
+    }
     if (comm->size == 1 || !halo_on) return;
     const long n = (long)nplanes * row_len;
     const int nb = vec_blocks(n);
@@ -474,7 +492,7 @@ struct Engine {
   std::vector<double*> liftm_hyb0, liftm_hyb1;         // per stage: hybrid preconditioner
   bool use_mfma_lift() const {
     static const bool off = std::getenv("HDG_NO_MFMA_LIFT") != nullptr;
-    return !off && cfg.degree >= 3;
+    return !off && cfg.degree >= 3 && !periodic;  // the matrix-core kernels do not wrap column indices
   }
   void lift_mfma(const double* t0, const double* t1, const double* in, double* out) {
     const dim3 grid(8 * g.rows_xcd * 2);
@@ -521,7 +539,7 @@ struct Engine {
     const double up = cfg.flux_upwind ? 1.0 : 0.0;
     // k >= 3: the whole operator on the matrix cores (k_adv_mfma); HDG_NO_MFMA_ADV falls back to the per-thread kernels
     static const bool no_mfma_adv = std::getenv("HDG_NO_MFMA_ADV") != nullptr;
-    if (!no_mfma_adv && cfg.degree >= 3) {
+    if (!no_mfma_adv && cfg.degree >= 3 && !periodic) {
       if (!advm[0]) {
         if (dt.nqc != (cfg.degree == 3 ? 36 : 64)) throw std::string("cell quadrature size does not match the matrix-core advection kernel");
         for (int sh = 0; sh < 2; sh++) advm[sh] = upload(pack_adv_mfma(sh));
@@ -703,7 +721,7 @@ struct Engine {
   // ------------------------------------------------------------------ pressure mean shift
   void shift(double* p, double* l) {
     const double c0 = g.h / std::sqrt(2.0);  // integral of the mode-0 basis function = its "1" coefficient
-    const double vol = 1.0;                  // domain_volume (common.py:72-73)
+    const double vol = Ldom * Ldom;          // domain_volume (common.py:72-73)
     int nb = std::min(dot_blocks, vec_blocks(g.Nc));
     VecList<4> vl{};
     vl.p[0] = ones_c;
@@ -1280,7 +1298,30 @@ struct Engine {
     k_p1_prolong_add<<<grid, 64, 0, stream>>>(nc, mg_x[lev + 1], mg_x[lev]);
     p1_smooth(lev, nsw, true);
   }
-  void run_vcycle() { vcycle(0); }
+  void run_vcycle() { if (periodic) vcycle_periodic(0); else vcycle(0); }
+  // the same V(2,2) cycle on the periodic vertex grids (per-level kernels)
+  void vcycle_periodic(int lev) {
+    const int n = mg_n[lev];
+    const long nv = (long)n * n;
+    static const int nsw = std::getenv("HDG_MG_SWEEPS") ? std::atoi(std::getenv("HDG_MG_SWEEPS")) : 2;
+    static const int ncoarse = std::getenv("HDG_MG_COARSE") ? std::atoi(std::getenv("HDG_MG_COARSE")) : 6;
+    const dim3 grid((n + 63) / 64, n);
+    auto sweeps = [&](int cnt, bool reverse) {
+      for (int sw = 0; sw < cnt; sw++) {
+        k_p1p_rbgs<<<grid, 64, 0, stream>>>(n, mg_x[lev], mg_b[lev], reverse ? 1 : 0);
+        k_p1p_rbgs<<<grid, 64, 0, stream>>>(n, mg_x[lev], mg_b[lev], reverse ? 0 : 1);
+      }
+    };
+    zero(mg_x[lev], nv);
+    if (lev == (int)mg_n.size() - 1) { sweeps(ncoarse, false); sweeps(ncoarse, true); return; }
+    sweeps(nsw, false);
+    k_p1p_residual<<<grid, 64, 0, stream>>>(n, mg_x[lev], mg_b[lev], mg_r[lev]);
+    const int nc = mg_n[lev + 1];
+    k_p1p_restrict<<<dim3((nc + 63) / 64, nc), 64, 0, stream>>>(nc, mg_r[lev], mg_b[lev + 1]);
+    vcycle_periodic(lev + 1);
+    k_p1p_prolong_add<<<grid, 64, 0, stream>>>(nc, mg_x[lev + 1], mg_x[lev]);
+    sweeps(nsw, true);
+  }
   // z = M r for the condensed system
   void trace_precond(const double* r, double* z) {
     if (cfg.trace_precond == 0) {
@@ -1294,6 +1335,14 @@ struct Engine {
     // restriction to the vertex grid from OWNED edges only (no halo of wL2): the cut rows are completed when the
     // gathered blocks are assembled
     const int partial = mg_gather ? 1 : 0;
+    if (periodic) {
+      halo_L(wL2);
+      k_trace_to_p1p<<<corner_grid(), bs(), 0, stream>>>(g, NL, wL2, mg_b[0], dt.elen[0], dt.elen[2], dt.elen[1]);
+      run_vcycle();
+      k_p1p_to_trace<<<corner_grid(), bs(), 0, stream>>>(g, NL, mg_x[0], z, 1.0, dt.elen[0], dt.elen[2], dt.elen[1]);
+      cheb_smooth(r, z, false, nsm);
+      return;
+    }
     k_trace_to_p1<<<corner_grid_all(), bs(), 0, stream>>>(g_all, NL, wL2, mg_b[0], dt.elen[0], dt.elen[2], dt.elen[1], partial);
     if (mg_gather) {
       // every rank contributes its (ny+1) vertex rows; one kernel assembles the global vector from the blocks
@@ -1310,7 +1359,7 @@ struct Engine {
   void setup_trace_solver() {
     // null-space vector
     {
-      long ne = (long)g.nx * (g.ny + 1) + (long)(g.nx + 1) * g.ny + (long)g.nx * g.ny;
+      long ne = n_edges();
       std::vector<double> ones((size_t)ne * NL, 1.0);
       HIPCHECK(hipMemcpyAsync(hL_dev, ones.data(), sizeof(double) * ones.size(), hipMemcpyHostToDevice, stream));
       l_to_modal(hL_dev, tr_one);
@@ -1322,9 +1371,9 @@ struct Engine {
       int n = g.nx;
       while (true) {
         mg_n.push_back(n);
-        long nv = (long)(n + 1) * (n + 1);
+        long nv = periodic ? (long)n * n : (long)(n + 1) * (n + 1);
         mg_x.push_back(dalloc(nv)); mg_b.push_back(dalloc(nv)); mg_r.push_back(dalloc(nv));
-        if (n % 2 != 0 || n <= 2) break;
+        if (n % 2 != 0 || n <= 2 || (periodic && (n / 2) % 2 != 0)) break;  // periodic red-black sweeps need an even n
         n /= 2;
       }
     }
@@ -1768,6 +1817,7 @@ struct Engine {
   void cg_setup() {
     if (cg_ready) return;
     if (comm->size > 1) throw std::string("the continuous space (tracer, vorticity) is implemented for a single rank");
+    if (periodic) throw std::string("the continuous space (tracer, vorticity) is not implemented on the periodic mesh");
     const int p = K + 1;
     std::vector<real> xi, eta;
     triangleNodes(p, cfg.equispaced_nodes, xi, eta);
@@ -2000,7 +2050,10 @@ struct Engine {
   }
 
   // ------------------------------------------------------------------ host <-> device fields
-  long n_edges() const { return (long)g.nx * (g.ny + 1) + (long)(g.nx + 1) * g.ny + (long)g.nx * g.ny; }
+  long n_edges() const {
+    if (periodic) return 3L * g.nx * g.ny;
+    return (long)g.nx * (g.ny + 1) + (long)(g.nx + 1) * g.ny + (long)g.nx * g.ny;
+  }
   void put_Q(const double* host, double* modal) {
     HIPCHECK(hipMemcpyAsync(hQ_dev, host, sizeof(double) * NQb, hipMemcpyHostToDevice, stream));
     q_to_modal(hQ_dev, modal);
@@ -2046,7 +2099,8 @@ struct Engine {
         for (int i = 0; i < g.nx; i++)
           for (int sh = 0; sh < 2; sh++) {
             const long c = 2 * ((long)j * g.nx + i) + sh;
-            const double x0 = (sh == 0 ? i : i + 1) * g.h, y0 = (g.joff + (sh == 0 ? j : j + 1)) * g.h;
+            const int joff_true = periodic ? 0 : g.joff;
+            const double x0 = (sh == 0 ? i : i + 1) * g.h, y0 = (joff_true + (sh == 0 ? j : j + 1)) * g.h;
             const double sg = sh == 0 ? 1.0 : -1.0;
             for (long n = 0; n < nn; n++) {
               out[(c * nn + n) * 2 + 0] = x0 + sg * g.h * (double)xi[n];

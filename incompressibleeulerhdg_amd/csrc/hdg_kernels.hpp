@@ -44,7 +44,15 @@ struct Geo {
   int rows_xcd;  // cell rows per XCD band      = ceil(ny / 8)
   int rows_xcdc; // corner rows per XCD band    = ceil((ny+1) / 8)
   int dbg_nonbr; // experiment switch (HDG_DBG_NONBR, timing only): every edge is treated as a boundary edge
+  // Doubly periodic square (PeriodicSquareMesh, driver.py:182-183; SURVEY.md section 8(f) row 2, first step).
+  //   x: px != 0 -> column indices wrap (only lanes 0 / nx-1 take another address); corner kernels run nx columns.
+  //   y: no kernel knows about it: the engine pretends that the strip lies in the middle of a taller mesh (joff = ny,
+  //      nyg = 3 ny: every physical-boundary test in y is false) and fills the ghost rows from the opposite side of
+  //      the strip before every stencil operator, exactly as it would from a neighbouring rank.
+  int px;
 };
+__device__ __forceinline__ int xm1(const Geo& g, int i) { return i > 0 ? i - 1 : g.nx - 1; }       // column to the left
+__device__ __forceinline__ int xp1(const Geo& g, int i) { return (g.px && i == g.nx - 1) ? 0 : i + 1; }  // column to the right
 
 template <int K>
 struct Dim {
@@ -84,11 +92,11 @@ __device__ __forceinline__ bool nbr(int s, int e, int i, int j, const Geo& g, lo
   if (s == 0) {
     if (e == 0) { in = i; jn = j - 1; ok = (g.joff + j) > 0; }
     else if (e == 1) { in = i; jn = j; ok = true; }
-    else { in = i - 1; jn = j; ok = i > 0; }
+    else { in = xm1(g, i); jn = j; ok = i > 0 || g.px; }
   } else {
     if (e == 0) { in = i; jn = j + 1; ok = (g.joff + j) < g.nyg - 1; }
     else if (e == 1) { in = i; jn = j; ok = true; }
-    else { in = i + 1; jn = j; ok = i < g.nx - 1; }
+    else { in = xp1(g, i); jn = j; ok = i < g.nx - 1 || g.px; }
   }
   cn = ((long)(1 - s) * (g.ny + 2) + (jn + 1)) * g.nx + in;
   return ok;
@@ -99,7 +107,7 @@ __device__ __forceinline__ long edge_off(int s, int e, int i, int j, const Geo& 
   if (e == 0) { t = 0; return (long)(j + s + 1) * g.P + i; }
   if (e == 1) { t = 2; return (long)(j + 1) * g.P + i; }
   t = 1;
-  return (long)(j + 1) * g.P + i + s;
+  return (long)(j + 1) * g.P + (s ? xp1(g, i) : i);
 }
 
 __device__ __forceinline__ long cidx(const Geo& g, int s, int j, int i) {
@@ -1074,11 +1082,13 @@ __global__ __launch_bounds__(128) void k_weak_div(Geo g, DevTables T, const doub
   const int jj_ = q_ / g.nbxc;                                     \
   const int i = (q_ - jj_ * g.nbxc) * blockDim.x + threadIdx.x;    \
   const int j = xcd_ * g.rows_xcdc + jj_;                          \
-  if (jj_ >= g.rows_xcdc || j >= g.nyc || i > g.nx) return;        \
+  if (jj_ >= g.rows_xcdc || j >= g.nyc || i > g.nx - g.px) return; \
   const long o = (long)(j + 1) * g.P + i;                          \
   const bool in_x = i < g.nx, in_y = j < g.ny;                     \
   const bool below = (g.joff + j) > 0;                             \
-  (void)below;
+  const bool left = i > 0 || g.px;          /* a cell column to the left exists */ \
+  const long oL = (long)(j + 1) * g.P + xm1(g, i), oR = (long)(j + 1) * g.P + xp1(g, i); /* corners (i-1, j), (i+1, j) */ \
+  (void)below; (void)left; (void)oL; (void)oR;
 
 template <int NL>
 __device__ __forceinline__ void load_tr(const double* __restrict__ l, const Geo& g, int t, long off, double* v) {
@@ -1092,6 +1102,8 @@ template <int K>
 __device__ __forceinline__ void trace_stencil(const Geo& g, const DevTables& T, const double* __restrict__ lam, long o, int i,
                                               bool in_x, bool in_y, bool below, double* own, double* yH, double* yV,
                                               double* yD) {
+  const bool left = i > 0 || g.px;
+  const long oL = o - i + xm1(g, i), oR = o - i + xp1(g, i);
   constexpr int NL = Dim<K>::NL, NT = 3 * NL;
 #pragma unroll
   for (int m = 0; m < NL; m++) yH[m] = yV[m] = yD[m] = 0.0;
@@ -1109,7 +1121,7 @@ __device__ __forceinline__ void trace_stencil(const Geo& g, const DevTables& T, 
     load_tr<NL>(lam, g, 0, o + g.P, u);
 #pragma unroll
     for (int m = 0; m < NL; m++) u[NL + m] = own[NL + m];
-    load_tr<NL>(lam, g, 1, o + 1, u + 2 * NL);
+    load_tr<NL>(lam, g, 1, oR, u + 2 * NL);
     mv_acc_ld<NL, NT>(SU + 1 * NL * NT, NT, u, yD, -1.0);
   }
   if (in_x && below) {  // U(i,j-1): edges (H(i,j), D(i,j-1), V(i+1,j-1)), row block e0 -> H
@@ -1117,13 +1129,13 @@ __device__ __forceinline__ void trace_stencil(const Geo& g, const DevTables& T, 
 #pragma unroll
     for (int m = 0; m < NL; m++) u[m] = own[m];
     load_tr<NL>(lam, g, 2, o - g.P, u + NL);
-    load_tr<NL>(lam, g, 1, o - g.P + 1, u + 2 * NL);
+    load_tr<NL>(lam, g, 1, oR - g.P, u + 2 * NL);
     mv_acc_ld<NL, NT>(SU + 0 * NL * NT, NT, u, yH, -1.0);
   }
-  if (in_y && i > 0) {  // U(i-1,j): edges (H(i-1,j+1), D(i-1,j), V(i,j)), row block e2 -> V
+  if (in_y && left) {  // U(i-1,j): edges (H(i-1,j+1), D(i-1,j), V(i,j)), row block e2 -> V
     double u[NT];
-    load_tr<NL>(lam, g, 0, o + g.P - 1, u);
-    load_tr<NL>(lam, g, 2, o - 1, u + NL);
+    load_tr<NL>(lam, g, 0, oL + g.P, u);
+    load_tr<NL>(lam, g, 2, oL, u + NL);
 #pragma unroll
     for (int m = 0; m < NL; m++) u[2 * NL + m] = own[2 * NL + m];
     mv_acc_ld<NL, NT>(SU + 2 * NL * NT, NT, u, yV, -1.0);
@@ -1179,7 +1191,7 @@ __global__ __launch_bounds__(128) void k_trace_smooth(Geo g, DevTables T, const 
   trace_stencil<K>(g, T, v, o, i, in_x, in_y, below, own, y[0], y[1], y[2]);
   const bool valid[3] = {in_x, in_y, in_x && in_y};
   const int ownoff[3] = {0, 2 * NL, NL};  // own[] is in local-edge order (H, D, V)
-  const int var[3] = {(g.joff + j == 0) ? 1 : (g.joff + j == g.nyg ? 2 : 0), (i == 0) ? 1 : (i == g.nx ? 2 : 0), 0};
+  const int var[3] = {(g.joff + j == 0) ? 1 : (g.joff + j == g.nyg ? 2 : 0), g.px ? 0 : ((i == 0) ? 1 : (i == g.nx ? 2 : 0)), 0};
   double bb[3][NL], xo[3][NL];
 #pragma unroll
   for (int t = 0; t < 3; t++)
@@ -1221,7 +1233,7 @@ __global__ __launch_bounds__(128) void k_trace_cheb(Geo g, DevTables T, const do
     bool valid;
     int var;
     if (t == 0) { valid = in_x; var = (g.joff + j == 0) ? 1 : (g.joff + j == g.nyg ? 2 : 0); }
-    else if (t == 1) { valid = in_y; var = (i == 0) ? 1 : (i == g.nx ? 2 : 0); }
+    else if (t == 1) { valid = in_y; var = g.px ? 0 : ((i == 0) ? 1 : (i == g.nx ? 2 : 0)); }
     else { valid = in_x && in_y; var = 0; }
     if (!valid) continue;
     double rr[NL], z[NL];
@@ -1291,7 +1303,7 @@ __global__ __launch_bounds__(128) void k_condense(Geo g, DevTables T, const doub
     y_rows<K, HASW, HASP>(T.Y[1], 1, rw, rp, g.Nc, cU, yD);
   }
   if (in_x && below) y_rows<K, HASW, HASP>(T.Y[1], 0, rw, rp, g.Nc, cidx(g, 1, j - 1, i), yH);
-  if (in_y && i > 0) y_rows<K, HASW, HASP>(T.Y[1], 2, rw, rp, g.Nc, cidx(g, 1, j, i - 1), yV);
+  if (in_y && left) y_rows<K, HASW, HASP>(T.Y[1], 2, rw, rp, g.Nc, cidx(g, 1, j, xm1(g, i)), yV);
 #pragma unroll
   for (int m = 0; m < NL; m++) {
     const long iH = ((long)0 * NL + m) * g.G + o, iV = ((long)1 * NL + m) * g.G + o, iD = ((long)2 * NL + m) * g.G + o;
@@ -1365,7 +1377,7 @@ __global__ __launch_bounds__(128) void k_trace_recon(Geo g, DevTables T, const d
     bool valid, hasL, hasU;
     long cL, cU;
     if (t == 0) { valid = in_x; hasL = in_y; hasU = below; cL = cidx(g, 0, j, i); cU = cidx(g, 1, j - 1, i); }
-    else if (t == 1) { valid = in_y; hasL = in_x; hasU = i > 0; cL = cidx(g, 0, j, i); cU = cidx(g, 1, j, i - 1); }
+    else if (t == 1) { valid = in_y; hasL = in_x; hasU = left; cL = cidx(g, 0, j, i); cU = cidx(g, 1, j, xm1(g, i)); }
     else { valid = in_x && in_y; hasL = hasU = true; cL = cidx(g, 0, j, i); cU = cidx(g, 1, j, i); }
     double acc[NL];
 #pragma unroll
@@ -1556,7 +1568,7 @@ __global__ __launch_bounds__(128) void k_gamma_mu(Geo g, DevTables T, const doub
     bool valid, hasL, hasU;
     long cL, cU;
     if (t == 0) { valid = in_x; hasL = in_y; hasU = below; cL = cidx(g, 0, j, i); cU = cidx(g, 1, j - 1, i); }
-    else if (t == 1) { valid = in_y; hasL = in_x; hasU = i > 0; cL = cidx(g, 0, j, i); cU = cidx(g, 1, j, i - 1); }
+    else if (t == 1) { valid = in_y; hasL = in_x; hasU = left; cL = cidx(g, 0, j, i); cU = cidx(g, 1, j, xm1(g, i)); }
     else { valid = in_x && in_y; hasL = hasU = true; cL = cidx(g, 0, j, i); cU = cidx(g, 1, j, i); }
     double acc[NL];
 #pragma unroll
@@ -1638,14 +1650,16 @@ template <int K, bool TO_MODAL>
 __global__ void k_l_convert(Geo g, DevTables T, double* __restrict__ nodal, double* __restrict__ modal) {
   constexpr int NL = Dim<K>::NL;
   HDG_CORNER_PROLOGUE
-  const long NH = (long)g.nx * (g.ny + 1), NV = (long)(g.nx + 1) * g.ny;
+  // periodic square: the edges of the top row / right column are those of the bottom row / left column
+  const int nvx = g.nx + 1 - g.px;
+  const long NH = (long)g.nx * (g.ny + 1 - g.px), NV = (long)nvx * g.ny;
 #pragma unroll
   for (int t = 0; t < 3; t++) {
     bool valid;
     long eidx;
     double len;
     if (t == 0) { valid = in_x; eidx = (long)j * g.nx + i; len = T.elen[0]; }
-    else if (t == 1) { valid = in_y; eidx = NH + (long)j * (g.nx + 1) + i; len = T.elen[2]; }
+    else if (t == 1) { valid = in_y; eidx = NH + (long)j * nvx + i; len = T.elen[2]; }
     else { valid = in_x && in_y; eidx = NH + NV + (long)j * g.nx + i; len = T.elen[1]; }
     if (!valid) continue;
     double a[NL], b[NL];
@@ -2342,6 +2356,88 @@ __global__ void k_p1_assemble(int P, int ny, int st, const double* __restrict__ 
     double v = gathered[r * blk + (long)lr * st + i];
     if (partial && lr == 0 && r > 0) v += gathered[(r - 1) * blk + (long)ny * st + i];
     out[idx] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// P1 coarse space on the doubly periodic square: n x n vertices (vertex (i,j) at j*n + i, indices wrap), operator = the
+// full 5-point stencil (diagonal 4; singular: constants).  Same V-cycle as above, per-level kernels.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int pw(int a, int n) { return a < 0 ? a + n : (a >= n ? a - n : a); }
+__global__ void k_p1p_rbgs(int n, double* __restrict__ x, const double* __restrict__ b, int colour) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
+  if (i >= n || ((i + j) & 1) != colour) return;
+  const double off = x[j * n + pw(i - 1, n)] + x[j * n + pw(i + 1, n)] + x[pw(j - 1, n) * n + i] + x[pw(j + 1, n) * n + i];
+  x[j * n + i] = (b[j * n + i] + off) * 0.25;
+}
+__global__ void k_p1p_residual(int n, const double* __restrict__ x, const double* __restrict__ b, double* __restrict__ r) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
+  if (i >= n) return;
+  const double off = x[j * n + pw(i - 1, n)] + x[j * n + pw(i + 1, n)] + x[pw(j - 1, n) * n + i] + x[pw(j + 1, n) * n + i];
+  r[j * n + i] = b[j * n + i] - (4.0 * x[j * n + i] - off);
+}
+__global__ void k_p1p_restrict(int nc, const double* __restrict__ rf, double* __restrict__ rc) {
+  const int I = blockIdx.x * blockDim.x + threadIdx.x, J = blockIdx.y;
+  if (I >= nc) return;
+  const int nf = 2 * nc, i = 2 * I, j = 2 * J;
+  const int im = pw(i - 1, nf), ip = pw(i + 1, nf), jm = pw(j - 1, nf), jp = pw(j + 1, nf);
+  rc[J * nc + I] = rf[j * nf + i] + 0.5 * (rf[j * nf + im] + rf[j * nf + ip] + rf[jm * nf + i] + rf[jp * nf + i] + rf[jp * nf + im] + rf[jm * nf + ip]);
+}
+__global__ void k_p1p_prolong_add(int nc, const double* __restrict__ xc, double* __restrict__ xf) {
+  const int nf = 2 * nc;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
+  if (i >= nf) return;
+  const int I = i >> 1, J = j >> 1, I1 = pw(I + 1, nc), J1 = pw(J + 1, nc);
+  double v;
+  if (!(i & 1) && !(j & 1)) v = xc[J * nc + I];
+  else if ((i & 1) && !(j & 1)) v = 0.5 * (xc[J * nc + I] + xc[J * nc + I1]);
+  else if (!(i & 1) && (j & 1)) v = 0.5 * (xc[J * nc + I] + xc[J1 * nc + I]);
+  else v = 0.5 * (xc[J * nc + I1] + xc[J1 * nc + I]);
+  xf[j * nf + i] += v;
+}
+// trace <-> periodic P1 grid (ghost trace rows must be current for the restriction)
+__global__ void k_p1p_to_trace(Geo g, int NL, const double* __restrict__ xc, double* __restrict__ l, double accumulate,
+                               double lH, double lV, double lD) {
+  HDG_CORNER_PROLOGUE
+  const int n = g.nx, i1 = pw(i + 1, n), j1 = pw(j + 1, n);
+  const double r3 = 0.57735026918962576451;
+  const double v00 = xc[j * n + i], v10 = xc[j * n + i1], v01 = xc[j1 * n + i];
+  const double ea[3] = {v00, v00, v10}, eb[3] = {v10, v01, v01}, len[3] = {lH, lV, lD};
+#pragma unroll
+  for (int t = 0; t < 3; t++) {
+    const double sl = sqrt(len[t]);
+    double* p0 = l + ((long)t * NL) * g.G + o;
+    double* p1 = l + ((long)t * NL + 1) * g.G + o;
+    *p0 = accumulate * (*p0) + sl * 0.5 * (ea[t] + eb[t]);
+    *p1 = accumulate * (*p1) + sl * r3 * 0.5 * (eb[t] - ea[t]);
+  }
+}
+__global__ void k_trace_to_p1p(Geo g, int NL, const double* __restrict__ l, double* __restrict__ rc, double lH, double lV, double lD) {
+  HDG_CORNER_PROLOGUE
+  const double r3 = 0.57735026918962576451;
+  const double* H0 = l + ((long)0 * NL) * g.G;
+  const double* H1 = l + ((long)0 * NL + 1) * g.G;
+  const double* V0 = l + ((long)1 * NL) * g.G;
+  const double* V1 = l + ((long)1 * NL + 1) * g.G;
+  const double* D0 = l + ((long)2 * NL) * g.G;
+  const double* D1 = l + ((long)2 * NL + 1) * g.G;
+  const double sH = 0.5 * sqrt(lH), sV = 0.5 * sqrt(lV), sD = 0.5 * sqrt(lD);
+  double acc = sH * (H0[o] - r3 * H1[o]) + sH * (H0[oL] + r3 * H1[oL])          // H(i,j) a-end, H(i-1,j) b-end
+             + sV * (V0[o] - r3 * V1[o]) + sV * (V0[o - g.P] + r3 * V1[o - g.P])  // V(i,j) a-end, V(i,j-1) b-end (ghost row for j = 0)
+             + sD * (D0[oL] - r3 * D1[oL]) + sD * (D0[o - g.P] + r3 * D1[o - g.P]);  // D(i-1,j) a-end, D(i,j-1) b-end
+  rc[j * g.nx + i] = acc;
+}
+// periodic strip on one rank: the ghost rows are the owned rows of the opposite side (array rows: 0 ghost below,
+// 1..ny owned, ny+1 ghost above)
+__global__ void k_wrap_rows(double* __restrict__ v, long plane_stride, int row_len, int nplanes, int ny) {
+  const long n = (long)nplanes * row_len;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += stride) {
+    const long pl = idx / row_len;
+    const int i = (int)(idx - pl * row_len);
+    double* p = v + pl * plane_stride;
+    p[i] = p[(long)ny * row_len + i];                       // below <- top owned row
+    p[(long)(ny + 1) * row_len + i] = p[(long)row_len + i];  // above <- bottom owned row
   }
 }
 

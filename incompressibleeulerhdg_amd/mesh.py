@@ -7,7 +7,7 @@ to the timestepper constructors; ``driver.py`` and ``model_problems.py`` then re
 
 import numpy as np
 
-__all__ = ["UnitSquareMesh", "FunctionSpace", "Function"]
+__all__ = ["UnitSquareMesh", "PeriodicSquareMesh", "FunctionSpace", "Function"]
 
 
 class UnitSquareMesh:
@@ -18,9 +18,21 @@ class UnitSquareMesh:
             raise NotImplementedError("only triangular meshes (driver.py:181)")
         self.nx = int(nx)
         self.ny = int(nx if ny is None else ny)
+        self.periodic = False
+        self.L = 1.0
 
     def num_cells(self):
         return 2 * self.nx * self.ny
+
+
+class PeriodicSquareMesh(UnitSquareMesh):
+    """Doubly periodic square of side L, ``PeriodicSquareMesh(nx, nx, L=2 * pi, quadrilateral=False)`` (src/driver.py:182-183):
+    the same triangulation, edges on opposite sides identified."""
+
+    def __init__(self, nx, ny=None, L=1.0, quadrilateral=False):
+        super().__init__(nx, ny, quadrilateral)
+        self.periodic = True
+        self.L = float(L)
 
 
 class _Dat:

@@ -1,13 +1,14 @@
 """Model problems as node-evaluated arrays (reference: src/model_problems.py:10-105).
 
-Only the manufactured Taylor-Green vortex is in scope.
+The manufactured Taylor-Green vortex (model_problems.py:38-105) and the double-layer shear flow on the periodic
+square (:134-196); the Kelvin-Helmholtz problem needs the unstructured disk mesh and is out of scope.
 """
 
 import numpy as np
 
 from .mesh import Function
 
-__all__ = ["TaylorGreen", "SeparableForcing"]
+__all__ = ["TaylorGreen", "DoubleLayerShearFlow", "SeparableForcing"]
 
 
 class SeparableForcing:
@@ -65,3 +66,41 @@ class TaylorGreen:
         if integrate_pressure is not None:
             p = p - integrate_pressure(p)  # model_problems.py:104: no division by the volume
         return Function(self.V_Q, Q, "velocity_exact"), Function(self.V_p, p, "pressure_exact")
+
+
+class DoubleLayerShearFlow:
+    """Double layer shear flow (model_problems.py:134-196; Guzman, Shu, Sequeira, IMA J. Numer. Anal. 37 (2017)) on the
+    periodic square [0, 2 pi]^2: two tanh shear layers of width rho perturbed by a vertical velocity of magnitude delta;
+    the initial pressure is the 28-term Fourier series of the reference, its coefficients by scipy.integrate.quad."""
+
+    def __init__(self, V_Q, V_p, rho=np.pi / 15, delta=0.05):
+        from scipy import integrate
+
+        self.V_Q, self.V_p = V_Q, V_p
+        self.rho, self.delta = rho, delta
+        self.Q_initial = lambda x, y: (np.where(y <= np.pi, np.tanh((y - np.pi / 2) / rho), np.tanh((1.5 * np.pi - y) / rho)),
+                                       delta * np.sin(x))
+        kmax = 28  # number of Fourier coefficients (model_problems.py:164)
+        coef = []
+        for k in range(kmax):
+            c = integrate.quad(
+                lambda z: np.where(z <= 0.0, 1 - np.tanh((np.pi + 2 * z) / (4 * np.pi * rho)) ** 2,
+                                   -1 + np.tanh((np.pi - 2 * z) / (4 * np.pi * rho)) ** 2) / (np.pi ** 2 * rho),
+                -np.pi, +np.pi, weight="sin", wvar=2 * k + 1, epsabs=1e-12, epsrel=1e-12)[0]
+            coef.append(c / (1 + (2 * k + 1) ** 2))
+        self._coef = coef
+
+        def p_initial(x, y):
+            acc = 0.0
+            for k, c in enumerate(self._coef):
+                acc = acc + c * np.sin((2 * k + 1) * (y - np.pi))
+            return acc * delta * np.cos(x)
+
+        self.p_initial = p_initial
+
+    def initial_condition(self):
+        return self.Q_initial, self.p_initial
+
+    def f_rhs(self):
+        """Zero forcing (model_problems.py:194-196)."""
+        return None

@@ -19,11 +19,11 @@ import numpy as np
 __all__ = ["VTKFile", "cell_vertex_nodes"]
 
 
-def _cell_vertices(nx, ny):
+def _cell_vertices(nx, ny, L=1.0):
     """Vertex coordinates (ncells, 3, 2) of the structured triangulation, cell c = 2 (j nx + i) + s:
     s = 0 lower-left triangle (x_i,y_j), (x_i+1,y_j), (x_i,y_j+1); s = 1 its point reflection
     (x_i+1,y_j+1), (x_i,y_j+1), (x_i+1,y_j)  (numbering documented in oracle/fem.py and DESIGN.md)."""
-    hx, hy = 1.0 / nx, 1.0 / ny
+    hx, hy = L / nx, L / ny
     jj, ii = np.meshgrid(np.arange(ny), np.arange(nx), indexing="ij")
     x0, y0 = (ii * hx).ravel(), (jj * hy).ravel()
     x1, y1 = x0 + hx, y0 + hy
@@ -40,8 +40,8 @@ def cell_vertex_nodes(space):
     mesh = space.mesh()
     ncells = mesh.num_cells()
     X = np.asarray(space.coordinates).reshape(ncells, -1, 2)
-    verts = _cell_vertices(mesh.nx, mesh.ny)
-    tol = 1e-9 / max(mesh.nx, mesh.ny)
+    verts = _cell_vertices(mesh.nx, mesh.ny, getattr(mesh, "L", 1.0))
+    tol = 1e-9 * getattr(mesh, "L", 1.0) / max(mesh.nx, mesh.ny)
     idx = np.empty((2, 3), dtype=int)
     for s in range(2):
         for v in range(3):
@@ -89,7 +89,7 @@ class VTKFile:
         mesh = functions[0].function_space().mesh()
         ncells = mesh.num_cells()
         pts = np.zeros((ncells * 3, 3), dtype="<f8")
-        pts[:, :2] = _cell_vertices(mesh.nx, mesh.ny).reshape(-1, 2)
+        pts[:, :2] = _cell_vertices(mesh.nx, mesh.ny, getattr(mesh, "L", 1.0)).reshape(-1, 2)
         conn = np.arange(ncells * 3, dtype="<i4")
         offs = np.arange(3, 3 * ncells + 1, 3, dtype="<i4")
         types = np.full(ncells, 5, dtype="<u1")  # VTK_TRIANGLE

@@ -28,11 +28,12 @@ class IncompressibleEuler(ABC):
         self._label = label
         self._engine_options = engine_options
         self._engine = None
-        self.domain_volume = 1.0  # common.py:72-73 on the unit square
+        self.domain_volume = float(getattr(mesh, "L", 1.0)) ** 2  # common.py:72-73
 
     # -- engine and function spaces ------------------------------------------------------------
     def _create_engine(self, **kw):
-        opts = dict(nx=self._mesh.nx, ny=self._mesh.ny, degree=self.degree, dt=self._dt)
+        opts = dict(nx=self._mesh.nx, ny=self._mesh.ny, degree=self.degree, dt=self._dt,
+                    periodic=getattr(self._mesh, "periodic", False), length=getattr(self._mesh, "L", 1.0))
         opts.update(kw)
         opts.update(self._engine_options)
         self._engine = Engine(**opts)

@@ -211,11 +211,17 @@ class PolySpace1D:
 # mesh
 # --------------------------------------------------------------------------------------
 class Mesh:
-    """Structured triangulation of the unit square (see module docstring)."""
+    """Structured triangulation of the unit square (see module docstring).
 
-    def __init__(self, nx):
+    ``periodic=True``: the doubly periodic square of side L (reference: ``PeriodicSquareMesh(nx, nx, L=2 pi)``,
+    src/driver.py:182-183).  Same cells; the edges on the top / right side are identified with those on the bottom /
+    left side, so there are nx*nx edges of each type, no boundary edges, and neighbour relations wrap around."""
+
+    def __init__(self, nx, periodic=False, L=1.0):
         self.nx = nx
-        h = 1.0 / nx
+        self.periodic = bool(periodic)
+        self.L = float(L)
+        h = self.L / nx
         self.h = h
         nc = 2 * nx * nx
         self.ncells = nc
@@ -231,8 +237,9 @@ class Mesh:
         self.detJ = np.abs(np.linalg.det(self.J))
         self.Jinv = np.linalg.inv(self.J)
         # edges
-        NH = nx * (nx + 1)
-        NV = nx * (nx + 1)
+        nrow = nx if self.periodic else nx + 1  # rows of H edges = columns of V edges
+        NH = nx * nrow
+        NV = nx * nrow
         ND = nx * nx
         self.nedges = NH + NV + ND
         a = np.zeros((self.nedges, 2))
@@ -241,17 +248,19 @@ class Mesh:
         cm = -np.ones(self.nedges, dtype=int)
 
         def cell(i, j, s):
+            if self.periodic:
+                return 2 * ((j % nx) * nx + (i % nx)) + s
             return 2 * (j * nx + i) + s if (0 <= i < nx and 0 <= j < nx) else -1
 
-        for j in range(nx + 1):
+        for j in range(nrow):
             for i in range(nx):
                 e = j * nx + i
                 a[e] = (i * h, j * h)
                 b[e] = ((i + 1) * h, j * h)
                 cp[e], cm[e] = cell(i, j, 0), cell(i, j - 1, 1)
         for j in range(nx):
-            for i in range(nx + 1):
-                e = NH + j * (nx + 1) + i
+            for i in range(nrow):
+                e = NH + j * nrow + i
                 a[e] = (i * h, j * h)
                 b[e] = (i * h, (j + 1) * h)
                 cp[e], cm[e] = cell(i, j, 0), cell(i - 1, j, 1)
@@ -281,4 +290,6 @@ class Mesh:
     def ref_coords(self, cells, x):
         """Reference coordinates in `cells` ([m]) of physical points x ([m, q, 2])."""
         d = x - self.cell_vertices[cells, 0][:, None, :]
+        if self.periodic:  # the point may be given in the other copy of the cell
+            d = (d + 0.5 * self.L) % self.L - 0.5 * self.L
         return np.einsum("mrd,mqd->mqr", self.Jinv[cells], d)

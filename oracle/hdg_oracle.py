@@ -45,8 +45,8 @@ class HDGDiscretisation:
     Reference: hdg_imex.py:65-70 (spaces), :313-365 (forms), common.py:36-57 (1/h_F).
     """
 
-    def __init__(self, nx, degree, variant="gll", tau=1.0, alpha_penalty=1.0):
-        self.mesh = mesh = Mesh(nx)
+    def __init__(self, nx, degree, variant="gll", tau=1.0, alpha_penalty=1.0, periodic=False, L=1.0):
+        self.mesh = mesh = Mesh(nx, periodic=periodic, L=L)
         self.k = k = degree
         self.tau = float(tau)  # hdg_imex.py:58
         self.alpha = float(alpha_penalty)  # hdg_imex.py:56
@@ -227,9 +227,12 @@ class HDGDiscretisation:
         self.Wdiv = self._assemble_weak_divergence()
 
         # --- null-space vector (hdg_imex.py:480-489) and bordered mixed-Poisson factorisation
-        z = np.concatenate([np.zeros(self.NQ), np.ones(self.NP), np.ones(self.NL)])
+        # Bordering: the column is the LEFT null vector (0, -1, 1) (never in the range of K), the row fixes the mean of phi.
+        # (A column equal to the right null vector (0, 1, 1) is orthogonal to the left one when NP == NL -- the periodic
+        # mesh at k = 1 -- and the bordered matrix is then singular.)
+        yl = np.concatenate([np.zeros(self.NQ), -np.ones(self.NP), np.ones(self.NL)])
         cvec = np.concatenate([np.zeros(self.NQ), self.int_p, np.zeros(self.NL)])
-        Kb = sp.bmat([[self.K_mp, sp.csc_matrix(z[:, None])], [sp.csc_matrix(cvec[None, :]), None]], format="csc")
+        Kb = sp.bmat([[self.K_mp, sp.csc_matrix(yl[:, None])], [sp.csc_matrix(cvec[None, :]), None]], format="csc")
         self._lu_mp = spla.splu(Kb)
 
     def _assemble_weak_divergence(self):
@@ -760,9 +763,9 @@ class OracleHDGIMEX:
 
 def _solve_singular(d, K, rhs):
     """Direct solve of a system whose null space is the constant (phi, lambda) shift."""
-    z = np.concatenate([np.zeros(d.NQ), np.ones(d.NP), np.ones(d.NL)])
+    yl = np.concatenate([np.zeros(d.NQ), -np.ones(d.NP), np.ones(d.NL)])  # left null vector (see _build_constant_operators)
     cvec = np.concatenate([np.zeros(d.NQ), d.int_p, np.zeros(d.NL)])
-    Kb = sp.bmat([[K, sp.csc_matrix(z[:, None])], [sp.csc_matrix(cvec[None, :]), None]], format="csc")
+    Kb = sp.bmat([[K, sp.csc_matrix(yl[:, None])], [sp.csc_matrix(cvec[None, :]), None]], format="csc")
     return spla.spsolve(Kb, np.concatenate([rhs, [0.0]]))[:-1]
 
 

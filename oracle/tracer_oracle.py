@@ -34,7 +34,9 @@ class TracerOracle:
         nc, nu = m.ncells, d.nu
         # ---- continuous space CG_{k+1}: identify coincident nodes of the broken space
         X = d.node_coords(d.PU).reshape(-1, 2)
-        key = np.round(X * (m.nx * 1e6)).astype(np.int64)
+        key = np.round(X * (m.nx * 1e6 / m.L)).astype(np.int64)
+        if m.periodic:
+            key = key % int(round(m.nx * 1e6))
         _, first, inv = np.unique(key, axis=0, return_index=True, return_inverse=True)
         self.cg_of_dg = inv.reshape(-1)  # [nc*nu] -> CG dof
         self.ncg = int(self.cg_of_dg.max()) + 1
