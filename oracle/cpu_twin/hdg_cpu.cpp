@@ -458,7 +458,7 @@ struct Twin {
     }
   }
   void vcycle(int lev) {
-    const int n = mg_n[lev], nsw = 2, ncoarse = 6;
+    const int n = mg_n[lev], nsw = 2, ncoarse = 2;
     std::fill(mg_x[lev].begin(), mg_x[lev].end(), 0.0);
     if (lev == (int)mg_n.size() - 1) { smooth(lev, ncoarse, false); smooth(lev, ncoarse, true); return; }
     smooth(lev, nsw, false);
