@@ -69,6 +69,7 @@ struct Engine {
   double Ldom = 1.0;      // side of the square
   Geo g_all;           // same strip, but corner kernels visit every local row 0..ny (conversions)
   double *hb_slo = nullptr, *hb_shi = nullptr, *hb_rlo = nullptr, *hb_rhi = nullptr;  // halo buffers
+  size_t cap_halo = 0;
   double* mg_gather = nullptr;
   Tables* tab = nullptr;
   DevTables dt;
@@ -247,6 +248,7 @@ struct Engine {
     Ldom = c.length > 0 ? c.length : 1.0;
     if (periodic && comm->size > 1) throw std::string("the periodic mesh is implemented for a single rank");
     if (periodic && (c.nx % 2 != 0)) throw std::string("the periodic mesh needs an even nx (red-black coarse-grid sweeps)");
+    if (periodic && g.ny < GHT) throw std::string("the periodic mesh needs at least 4 cell rows");
     if (periodic) {
       // y-periodicity without touching a kernel: the strip pretends to lie in the middle of a taller mesh (no physical
       // boundary test in y fires, the top H row is a ghost copy of the bottom one like on a rank below another) and its
@@ -255,8 +257,9 @@ struct Engine {
     }
     g.px = periodic ? 1 : 0;
     g.P = ((c.nx + 1 + 15) / 16) * 16;
-    g.G = (long)(g.ny + 2) * g.P;
-    g.Nc = 2L * c.nx * (g.ny + 2);
+    g.G = (long)(g.ny + 2 * GHT) * g.P;
+    g.Nc = 2L * c.nx * (g.ny + 2 * GH);
+    g.elo = g.ehi = 0;
     g.h = Ldom / c.nx;
     g.nbx = (g.nx + bs() - 1) / bs();
     g.nbxc = (g.nx + 1 + bs() - 1) / bs();
@@ -358,7 +361,8 @@ struct Engine {
     hQ_dev = dalloc(NQb); hP_dev = dalloc(NPb);
     hL_dev = dalloc(NLb);
     {
-      long cap = std::max<long>(2L * NU * 2L * g.nx, 3L * NL * g.P);
+      long cap = std::max<long>(GH * 2L * NU * 2L * g.nx, GHT * 3L * NL * g.P);  // up to GH / GHT rows per message
+      cap_halo = (size_t)cap;
       hb_slo = dalloc(cap); hb_shi = dalloc(cap); hb_rlo = dalloc(cap); hb_rhi = dalloc(cap);
     }
     for (int i = 0; i < s; i++) { dinv0.push_back(nullptr); dinv1.push_back(nullptr); hybg0.push_back(nullptr); hybg1.push_back(nullptr); dinv_gamma.push_back(-1.0); }
@@ -379,26 +383,38 @@ struct Engine {
   // consistent copies consistent.)
   bool halo_on = true;  // switched off while timing bare kernel launches (hdg_time_kernel is not collective)
   long n_halo[3] = {0, 0, 0}, n_reduce = 0, n_gather = 0;  // communication census (HDG_DEBUG, printed at destruction)
-  void halo_rows(double* v, long plane_stride, int row_len, int nplanes, int kind) {
+  void halo_rows(double* v, long plane_stride, int row_len, int nplanes, int kind, int depth = 1, int gh = GH) {
     if (periodic && halo_on) {  // ghost rows = the owned rows of the opposite side
-      k_wrap_rows<<<std::min(vec_blocks((long)nplanes * row_len), 512), 256, 0, stream>>>(v, plane_stride, row_len, nplanes, g.ny);
+      k_wrap_rows<<<std::min(vec_blocks((long)nplanes * row_len * gh), 512), 256, 0, stream>>>(v, plane_stride, row_len, nplanes, g.ny, gh);
       return;
     }
     if (comm->size == 1 || !halo_on) return;
-    const long n = (long)nplanes * row_len;
+    if (depth < 1 || depth > gh || depth > g.ny) throw std::string("halo depth out of range (a strip needs at least as many rows)");
+    const long n = (long)nplanes * row_len * depth;
+    if ((size_t)n > cap_halo) throw std::string("halo buffer too small");
     const int nb = vec_blocks(n);
     n_halo[kind]++;
-    // 3 launches per exchange: pack both rows, neighbour send/recv, unpack both rows
+    // 3 launches per exchange: pack both messages, neighbour send/recv, unpack both messages.  Array rows: owned rows are
+    // gh .. gh+ny-1; the lowest `depth` owned rows go down into the lower neighbour's rows gh+ny .. gh+ny+depth-1, the
+    // highest `depth` go up into the upper neighbour's rows gh-depth .. gh-1.
     const int nbh = std::min(nb, 256);
-    k_pack_rows<<<dim3(nbh, 2), 256, 0, stream>>>(v, plane_stride, row_len, nplanes, 1, g.ny, hb_slo, hb_shi);
+    k_pack_rows<<<dim3(nbh, 2), 256, 0, stream>>>(v, plane_stride, row_len, nplanes, depth, gh, gh + g.ny - depth, hb_slo, hb_shi);
     comm->exchange(hb_slo, hb_rlo, hb_shi, hb_rhi, (size_t)n, stream);
-    k_unpack_rows<<<dim3(nbh, 2), 256, 0, stream>>>(v, plane_stride, row_len, nplanes, comm->rank > 0 ? 0 : -1,
-                                                    comm->rank < comm->size - 1 ? g.ny + 1 : -1, hb_rlo, hb_rhi);
+    k_unpack_rows<<<dim3(nbh, 2), 256, 0, stream>>>(v, plane_stride, row_len, nplanes, depth, comm->rank > 0 ? gh - depth : -1,
+                                                    comm->rank < comm->size - 1 ? gh + g.ny : -1, hb_rlo, hb_rhi);
   }
-  // velocity: component-pair layout -> a row of one (mode, shape) plane is 2 nx doubles
-  void halo_Q(const double* v) { halo_rows(const_cast<double*>(v), 2L * (g.ny + 2) * g.nx, 2 * g.nx, NU * 2, 0); }
-  void halo_P(const double* v) { halo_rows(const_cast<double*>(v), (long)(g.ny + 2) * g.nx, g.nx, NP * 2, 1); }
-  void halo_L(const double* v) { halo_rows(const_cast<double*>(v), g.G, g.P, 3 * NL, 2); }
+  // velocity: component-pair layout -> a row of one (mode, shape) plane is 2 nx doubles.
+  // ghost_fresh: the vector whose first ghost rows the advection operator has just computed itself (adv_apply with
+  // extension): the next velocity exchange, if it is for that vector, is skipped.  One-shot: any other request clears it.
+  const double* ghost_fresh = nullptr;
+  void halo_Q(const double* v, int depth = 1) {
+    const bool skip = v == ghost_fresh && depth == 1;
+    ghost_fresh = nullptr;
+    if (skip) return;
+    halo_rows(const_cast<double*>(v), 2L * (g.ny + 2 * GH) * g.nx, 2 * g.nx, NU * 2, 0, depth);
+  }
+  void halo_P(const double* v) { halo_rows(const_cast<double*>(v), (long)(g.ny + 2 * GH) * g.nx, g.nx, NP * 2, 1); }
+  void halo_L(const double* v, int depth = 1) { halo_rows(const_cast<double*>(v), g.G, g.P, 3 * NL, 2, depth, GHT); }
 
   // ---- MFMA lift (k >= 3): tables in A-operand lane order for k_edge_lift_mfma.  Tile (mt, ks) of a matrix M:
   // 64 doubles, entry l = M[16 mt + l % 16][4 ks + l / 16] (zero outside M).  Order: W (2 M-tiles), N'_0..2, G.
@@ -534,8 +550,36 @@ struct Engine {
     halo_Q(in);
     HDG_DISPATCH(k_edge_lift<KK, true, 0><<<cell_grid(), bs(), 0, stream>>>(g, dt, in, out, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, 0.0, nullptr));
   }
+  // Inside a tentative-velocity solve (ExtScope) on several ranks the operator also computes the FIRST GHOST ROWS of
+  // its result: x is exchanged two rows deep, Q* and b carry valid ghost rows for the whole solve (ExtScope), and the
+  // edge-lift preconditioner that consumes `out` next finds its neighbour values in place (ghost_fresh): one
+  // exchange per Krylov / Chebyshev iteration instead of two, for 2 / ny more rows of operator work.
+  bool solve_ext = false;
+  struct ExtScope {
+    Engine& E;
+    bool mine = false;
+    ExtScope(Engine& e, const double* qstar, const double* b) : E(e) {
+      static const bool off = std::getenv("HDG_NO_EXT") != nullptr;
+      if (off || E.solve_ext || E.comm->size == 1 || !E.halo_on || E.g.ny < GH) return;
+      E.halo_Q(qstar);
+      E.halo_Q(b);
+      E.solve_ext = mine = true;
+    }
+    ~ExtScope() { if (mine) { E.solve_ext = false; E.ghost_fresh = nullptr; } }
+  };
   void adv_apply(const double* x, const double* qstar, double* out, double gamma, const double* bsub = nullptr) {
-    halo_Q(x);
+    const bool ext = solve_ext && halo_on;
+    Geo g = this->g;  // this launch's copy (row extension)
+    if (ext) {
+      g.elo = comm->rank > 0 ? 1 : 0;
+      g.ehi = comm->rank < comm->size - 1 ? 1 : 0;
+      g.rows_xcd = (g.ny + g.elo + g.ehi + 7) / 8;
+      halo_Q(x, 2);
+    } else {
+      halo_Q(x);
+    }
+    struct Fresh { Engine& E; const double* v; ~Fresh() { E.ghost_fresh = v; } } fresh_{*this, ext ? out : nullptr};
+    const dim3 cgrid(8 * g.rows_xcd * 2 * g.nbx, 1, 1);
     const double up = cfg.flux_upwind ? 1.0 : 0.0;
     // k >= 3: the whole operator on the matrix cores (k_adv_mfma); HDG_NO_MFMA_ADV falls back to the per-thread kernels
     static const bool no_mfma_adv = std::getenv("HDG_NO_MFMA_ADV") != nullptr;
@@ -561,7 +605,7 @@ struct Engine {
       HDG_DISPATCH(k_adv_apply2<KK><<<dim3(8 * g.rows_xcd * 2 * nbx2), bs(), 0, stream>>>(g, dt, x, qstar, out, gamma, up, bsub));
       return;
     }
-    HDG_DISPATCH(k_adv_apply<KK><<<cell_grid(), bs(), 0, stream>>>(g, dt, x, qstar, out, gamma, up, bsub));
+    HDG_DISPATCH(k_adv_apply<KK><<<cgrid, bs(), 0, stream>>>(g, dt, x, qstar, out, gamma, up, bsub));
   }
   void blockdiag(const double* D0, const double* D1, const double* r, const double* zin, double cz, double* out) {
     HDG_DISPATCH(k_blockdiag<KK><<<cell_grid(), bs(), 0, stream>>>(g, D0, D1, r, zin, cz, out));
@@ -576,19 +620,90 @@ struct Engine {
     if (broken) { HDG_DISPATCH(k_weak_div<KK, true><<<cell_grid(), bs(), 0, stream>>>(g, dt, q, sc, out)); }
     else { HDG_DISPATCH(k_weak_div<KK, false><<<cell_grid(), bs(), 0, stream>>>(g, dt, q, sc, out)); }
   }
-  void trace_apply(const double* lam, const double* base, double cb, double ct, double* out) {
-    halo_L(lam);
-    HDG_DISPATCH(k_trace_apply<KK><<<corner_grid(), bs(), 0, stream>>>(g, pdt(), lam, base, cb, ct, out));
+  // ---- ghost-row bookkeeping of the trace solver (strip partition).  Inside the preconditioned CG (tf.active) every
+  // trace vector carries the number of ghost rows on which it currently holds the right values.  A row stencil
+  // (operator, fused smoother step) reads its input one row beyond the rows it computes: it is launched over as many
+  // ghost rows as its inputs allow (Geo::elo / ehi) and its result is valid there; only an input with no valid ghost
+  // row triggers an exchange, tf.Dx rows deep.  Dx = 4 = GHT: the direction vector p is the only exchange of a CG
+  // iteration (operator on 3 ghost rows, pre-smoother 3 -> 2, coarse correction on 2, post-smoother 1 -> 0); Dx = 2
+  // (strips of 2-3 rows): two; Dx = 1 (HDG_NO_EXT, periodic, outside the CG): the classic exchange before every
+  // stencil, five per iteration.  Redundant work at Dx = 4: 18 row launches per iteration and side.
+  struct TraceFlow {
+    bool active = false;
+    int Dx = 1;
+    std::vector<std::pair<const double*, int>> v;
+    int get(const double* p) const {
+      for (const auto& e : v) if (e.first == p) return e.second;
+      return 0;
+    }
+    void set(const double* p, int d) {
+      for (auto& e : v) if (e.first == p) { e.second = d; return; }
+      v.emplace_back(p, d);
+    }
+  } tf;
+  struct TraceFlowScope {
+    Engine& E;
+    explicit TraceFlowScope(Engine& e) : E(e) {
+      static const bool off = std::getenv("HDG_NO_EXT") != nullptr;
+      E.tf.v.clear();
+      E.tf.active = true;
+      E.tf.Dx = (off || E.comm->size == 1 || E.periodic || !E.halo_on) ? 1 : std::min(GHT, E.g.ny);
+    }
+    ~TraceFlowScope() { E.tf.active = false; E.tf.v.clear(); }
+  };
+  // input of a row stencil: make sure at least one ghost row is valid; returns the rows the stencil may extend over
+  int tr_stencil_input(const double* in) {
+    if (!tf.active) { halo_L(in); return 0; }
+    if (tf.get(in) < 1) { halo_L(in, tf.Dx); tf.set(in, tf.Dx); }
+    return tf.get(in) - 1;
+  }
+  int tr_pointwise_input(const double* in, int ext) const { return (in && tf.active) ? std::min(ext, tf.get(in)) : (in ? 0 : ext); }
+  Geo gtr(int ext) const {
+    Geo c = g;
+    if (comm->size > 1 && ext > 0) {
+      c.elo = comm->rank > 0 ? ext : 0;
+      c.ehi = comm->rank < comm->size - 1 ? ext : 0;
+      c.rows_xcdc = (c.nyc + c.elo + c.ehi + 7) / 8;
+    }
+    return c;
+  }
+  static dim3 corner_grid_of(const Geo& c) { return dim3(8 * c.rows_xcdc * c.nbxc, 1, 1); }
+  void trace_apply(const double* lam, const double* base, double cb, double ct, double* out, int max_ext = GHT) {
+    int ext = std::min(tr_stencil_input(lam), max_ext);
+    if (cb != 0.0) ext = tr_pointwise_input(base, ext);
+    const Geo c = gtr(ext);
+    HDG_DISPATCH(k_trace_apply<KK><<<corner_grid_of(c), bs(), 0, stream>>>(c, pdt(), lam, base, cb, ct, out));
+    if (tf.active) tf.set(out, ext);
   }
   // fused smoother step (k_trace_smooth): r = cb*base + ct*(-S) v, z = Dinv r, dn = c1 v + c2 z, optional outputs
   void trace_smooth(const double* v, const double* base, double cb, double ct, double c1, double c2, double* r_out,
                     double* d_out, double* x, bool xadd, double xv) {
-    halo_L(v);
-    HDG_DISPATCH(k_trace_smooth<KK><<<corner_grid(), bs(), 0, stream>>>(g, pdt(), v, base, cb, ct, c1, c2, r_out, d_out, x,
-                                                                       xadd ? 1 : 0, xv));
+    int ext = tr_stencil_input(v);
+    if (cb != 0.0) ext = tr_pointwise_input(base, ext);
+    if (x && xadd) ext = tr_pointwise_input(x, ext);
+    const Geo c = gtr(ext);
+    HDG_DISPATCH(k_trace_smooth<KK><<<corner_grid_of(c), bs(), 0, stream>>>(c, pdt(), v, base, cb, ct, c1, c2, r_out, d_out, x,
+                                                                         xadd ? 1 : 0, xv));
+    if (tf.active) {
+      if (r_out) tf.set(r_out, ext);
+      if (d_out) tf.set(d_out, ext);
+      if (x) tf.set(x, ext);
+    }
   }
   void trace_cheb(const double* r, double* d, double* x, double c1, double c2, bool assign = false) {
-    HDG_DISPATCH(k_trace_cheb<KK><<<corner_grid(), bs(), 0, stream>>>(g, pdt(), r, d, x, c1, c2, assign ? 1 : 0));
+    int ext = tr_pointwise_input(r, GHT);
+    if (c1 != 0.0) ext = tr_pointwise_input(d, ext);
+    if (x && !assign) ext = tr_pointwise_input(x, ext);
+    const Geo c = gtr(ext);
+    HDG_DISPATCH(k_trace_cheb<KK><<<corner_grid_of(c), bs(), 0, stream>>>(c, pdt(), r, d, x, c1, c2, assign ? 1 : 0));
+    if (tf.active) { tf.set(d, ext); if (x) tf.set(x, ext); }
+  }
+  // z (+)= prolongation of the (replicated, global) vertex vector: pointwise, on every row on which z is valid
+  void p1_to_trace(const double* xc, double* z, double accumulate) {
+    const int ext = accumulate != 0.0 ? tr_pointwise_input(z, GHT) : (tf.active ? tf.Dx : 0);
+    const Geo c = gtr(ext);
+    k_p1_to_trace<<<corner_grid_of(c), bs(), 0, stream>>>(c, NL, xc, z, accumulate, dt.elen[0], dt.elen[2], dt.elen[1]);
+    if (tf.active) tf.set(z, ext);
   }
   void condense(const double* rw, const double* rp, const double* rl, double* out) {
     if (rw) halo_Q(rw);
@@ -677,9 +792,9 @@ struct Engine {
   // a row of a plane holds 2 nx doubles)
   enum { KC = 1, KL = 2, KQ = 3 };
   RowMask mask_for(int kind) const {
-    if (kind == KL) return RowMask{g.P, g.ny + 2, 1, g.nyc};
-    if (kind == KQ) return RowMask{2 * g.nx, g.ny + 2, 1, g.ny};
-    return RowMask{g.nx, g.ny + 2, 1, g.ny};
+    if (kind == KL) return RowMask{g.P, g.ny + 2 * GHT, GHT, GHT + g.nyc - 1};
+    if (kind == KQ) return RowMask{2 * g.nx, g.ny + 2 * GH, GH, GH + g.ny - 1};
+    return RowMask{g.nx, g.ny + 2 * GH, GH, GH + g.ny - 1};
   }
   // dots of w against nv vectors over the OWNED entries, summed over ranks (host result); one sync
   // cross: res[nv] additionally receives (V[0], V[1]) from the same pass (nv >= 2, single chunk)
@@ -855,6 +970,7 @@ struct Engine {
   int gmres(const double* qstar, double gamma, int didx, const double* b, double* x, double rtol = -1.0,
             int maxit = -1, bool strict = true, std::vector<std::complex<double>>* ritz = nullptr, int m_cycle = 0,
             double* beta_first = nullptr, double* beta_last = nullptr, double beta0_given = -1.0) {
+    ExtScope ext_(*this, qstar, b);
     const int m = std::min(std::max(1, cfg.gmres_restart), MAXV - 1);  // allocated basis / Hessenberg stride
     // adaptive cycle length: short cycles keep the Krylov-basis traffic low (the preconditioned operator
     // is benign: GMRES(4) needs 45.5 iterations where GMRES(30) needs 42.5 at C3); a cycle that reduces
@@ -1026,6 +1142,7 @@ struct Engine {
   std::vector<char> ch_slow;  // the last Chebyshev solve of the stage was slow: GMRES until the next re-estimate
   double* chd = nullptr;
   int cheb_gmres(const double* qstar, double gamma, int didx, const double* b, double* x) {
+    ExtScope ext_(*this, qstar, b);
     const double rtol = cfg.tent_rtol;
     if ((int)ch_lmin.size() < s + 1) { ch_lmin.assign(s + 1, -1.0); ch_lmax.assign(s + 1, -1.0); }
     if (!chd) chd = dalloc(NQ);
@@ -1332,7 +1449,7 @@ struct Engine {
     }
     static const int nsm = std::getenv("HDG_TRACE_SMOOTH_ITS") ? std::atoi(std::getenv("HDG_TRACE_SMOOTH_ITS")) : 2;
     cheb_smooth(r, z, true, nsm);
-    trace_apply(z, r, 1.0, -1.0, wL2);
+    trace_apply(z, r, 1.0, -1.0, wL2, 0);  // restricted from owned rows only: no extension
     // restriction to the vertex grid from OWNED edges only (no halo of wL2): the cut rows are completed when the
     // gathered blocks are assembled
     const int partial = mg_gather ? 1 : 0;
@@ -1341,6 +1458,7 @@ struct Engine {
       k_trace_to_p1p<<<corner_grid(), bs(), 0, stream>>>(g, NL, wL2, mg_b[0], dt.elen[0], dt.elen[2], dt.elen[1]);
       run_vcycle();
       k_p1p_to_trace<<<corner_grid(), bs(), 0, stream>>>(g, NL, mg_x[0], z, 1.0, dt.elen[0], dt.elen[2], dt.elen[1]);
+      if (tf.active) tf.set(z, 0);  // owned rows only: the wrapped ghost rows are stale
       cheb_smooth(r, z, false, nsm);
       return;
     }
@@ -1354,7 +1472,7 @@ struct Engine {
       k_p1_assemble<<<vec_blocks(nvtx), 256, 0, stream>>>(comm->size, g.ny, g.nx + 1, mg_gather, mg_b[0], partial);
     }
     run_vcycle();
-    k_p1_to_trace<<<corner_grid(), bs(), 0, stream>>>(g, NL, mg_x[0], z, 1.0, dt.elen[0], dt.elen[2], dt.elen[1]);
+    p1_to_trace(mg_x[0], z, 1.0);
     cheb_smooth(r, z, false, nsm);
   }
   void setup_trace_solver() {
@@ -1436,6 +1554,8 @@ struct Engine {
   // after the preconditioner -- by then it has long arrived.  2 blocking syncs per iteration become 0.
   int trace_cg_dev(double* b, double* x, double rtol, int maxit, bool strict) {
     project_const(b);
+    TraceFlowScope flow_(*this);
+    if (tf.Dx > 1) { halo_L(b, tf.Dx - 1); tf.set(b, tf.Dx - 1); }  // r = b - T x on the ghost rows the operator reaches
     trace_apply(x, b, 1.0, -1.0, cg_r);  // r = b - T x
     trace_precond(cg_r, cg_z);
     if (tr_one_nn < 0) tr_one_nn = dot(NLv, tr_one, tr_one, KL);
@@ -1455,6 +1575,7 @@ struct Engine {
       double zz = h_cgs[4];
       if (h_cgs[6] == 2.0) {
         axpby(NLv, -h_cgs[3], tr_one, 1.0, cg_z);
+        tf.set(cg_z, 0);
         zz = dot(NLv, cg_z, cg_z, KL);
         HIPCHECK(hipMemsetAsync(d_cgs + 6, 0, sizeof(double), stream));
         // the direction update that consumes this z has not been queued yet: it must not project a second time
@@ -1467,6 +1588,7 @@ struct Engine {
     const double norm0 = std::sqrt(std::max(snapshot_norm2(true), 0.0));
     if (norm0 == 0.0) return 0;
     k_cg_p_dev<<<nvb, 256, 0, stream>>>(NLv, cg_z, tr_one, d_cgs, cg_p);
+    tf.set(cg_p, 0);
     int its = 0;
     while (true) {
       trace_apply(cg_p, nullptr, 0.0, 1.0, cg_Ap);
@@ -1481,11 +1603,14 @@ struct Engine {
           return its;
         }
       }
-      k_cg_xr_dev<<<nvb, 256, 0, stream>>>(NLv, d_cgs, cg_p, cg_Ap, x, cg_r);
+      k_cg_xr_dev<<<nvb, 256, 0, stream>>>(NLv, d_cgs, cg_p, cg_Ap, x, cg_r);  // whole arrays: ghost rows follow
+      tf.set(cg_r, std::min(tf.get(cg_r), tf.get(cg_Ap)));
+      tf.set(x, 0);
       trace_precond(cg_r, cg_z);
       dots_and_snapshot(0);
       its++;
       k_cg_p_dev<<<nvb, 256, 0, stream>>>(NLv, cg_z, tr_one, d_cgs, cg_p);
+      tf.set(cg_p, 0);
     }
   }
   int trace_cg(double* b, double* x, double rtol = -1.0, int maxit = -1, bool strict = true) {
@@ -2230,7 +2355,7 @@ static int create_impl(const hdg_config* cfg, int rank, int nranks, int backend,
       const int k = cfg->degree;
       const size_t nu = (size_t)(k + 2) * (k + 3) / 2;
       const size_t P = ((size_t)cfg->nx + 1 + 15) / 16 * 16;
-      const size_t cap_halo = std::max<size_t>(2 * nu * 2 * cfg->nx, 3 * (size_t)(k + 1) * P);
+      const size_t cap_halo = std::max<size_t>(hdg::GH * 2 * nu * 2 * cfg->nx, hdg::GHT * 3 * (size_t)(k + 1) * P);
       const size_t cap_gather = ((size_t)cfg->ny / nranks + 1) * ((size_t)cfg->nx + 1);
       comm.reset(new hdg::CommShm(rank, nranks, token, cap_halo, cap_gather));
     } else return HDG_ERR_ARG;

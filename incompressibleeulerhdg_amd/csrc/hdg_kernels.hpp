@@ -24,16 +24,22 @@ namespace hdg {
 
 struct Geo {
   // Strip partition: a rank owns the cell rows joff .. joff+ny-1 of the global
-  // nx x nyg mesh.  Every array carries one GHOST row below (j = -1) and one above (j = ny):
-  //   cell index   c = (s*(ny+2) + (j+1))*nx + i          j in [-1, ny]
-  //   trace offset o = (j+1)*P + i                         corner rows j in [-1, ny]
+  // nx x nyg mesh.  Cell arrays carry GH = 2 GHOST rows below (j = -2, -1) and above (j = ny, ny+1), trace arrays GHT = 4:
+  //   cell index   c = (s*(ny+2GH) + (j+GH))*nx + i       j in [-GH, ny+GH-1]
+  //   trace offset o = (j+GHT)*P + i                       corner rows j in [-GHT, ny+GHT-1]
+  // Depth 1 serves every stencil operator; depth 2 of a velocity vector lets the advection operator compute its
+  // result on the first ghost rows as well (elo / ehi below), so that the edge-lift preconditioner that follows
+  // needs no exchange of its own: one exchange per Krylov / Chebyshev iteration instead of two.  The trace rows are
+  // deeper because one preconditioned CG iteration chains five row stencils (operator, two smoother steps before and
+  // after the coarse correction): with the direction vector exchanged four rows deep every one of them can run on
+  // rows whose inputs are still valid (Engine::TraceFlow), one exchange per CG iteration instead of five.
   // A rank computes the corner rows 0 .. nyc-1 (nyc = ny, or ny+1 on the topmost rank which also
   // owns the edges on the top boundary); row ny of the other ranks is a ghost copy of the upper
   // neighbour's row 0.  With one rank the ghost rows exist but are never referenced.
   int nx, ny, P;
   int nyg, joff, nyc;
-  long G;   // (ny+2)*P : one trace plane
-  long Nc;  // 2*nx*(ny+2): stride between dof planes of a cell vector
+  long G;   // (ny+2GHT)*P : one trace plane
+  long Nc;  // 2*nx*(ny+2GH): stride between dof planes of a cell vector
   double h;
   // XCD-aware block mapping (1-D grids): workgroups are dealt round-robin over the 8 XCDs, so
   // blockIdx % 8 labels the XCD.  Each XCD owns a contiguous band of mesh rows and walks it row by
@@ -50,7 +56,14 @@ struct Geo {
   //      nyg = 3 ny: every physical-boundary test in y is false) and fills the ghost rows from the opposite side of
   //      the strip before every stencil operator, exactly as it would from a neighbouring rank.
   int px;
+  // THIS launch also computes elo ghost rows below and ehi above the owned rows (rows_xcd / rows_xcdc of the copy
+  // cover the extended range).  Cell kernels: only the advection operator (Engine::adv_apply, 0 or 1); corner kernels:
+  // the operators of the trace solver (Engine::TraceFlow, up to GHT - 1).
+  int elo, ehi;
 };
+constexpr int GH = 2;   // ghost rows on either side of the strip in every cell / pressure array
+constexpr int GHT = 4;  // ... and in every trace array
+__device__ __forceinline__ long rowbase(const Geo& g, int s, int j) { return ((long)s * (g.ny + 2 * GH) + (j + GH)) * g.nx; }
 __device__ __forceinline__ int xm1(const Geo& g, int i) { return i > 0 ? i - 1 : g.nx - 1; }       // column to the left
 __device__ __forceinline__ int xp1(const Geo& g, int i) { return (g.px && i == g.nx - 1) ? 0 : i + 1; }  // column to the right
 
@@ -81,9 +94,9 @@ struct DevTables {
   const int jj_ = q_ / (2 * g.nbx), rem_ = q_ - jj_ * 2 * g.nbx;   \
   const int s = rem_ / g.nbx;                                      \
   const int i = (rem_ - s * g.nbx) * blockDim.x + threadIdx.x;     \
-  const int j = xcd_ * g.rows_xcd + jj_;                           \
-  if (jj_ >= g.rows_xcd || j >= g.ny || i >= g.nx) return;         \
-  const long c = ((long)s * (g.ny + 2) + (j + 1)) * g.nx + i;
+  const int j = xcd_ * g.rows_xcd + jj_ - g.elo;                   \
+  if (jj_ >= g.rows_xcd || j >= g.ny + g.ehi || i >= g.nx) return; \
+  const long c = rowbase(g, s, j) + i;
 
 __device__ __forceinline__ bool nbr(int s, int e, int i, int j, const Geo& g, long& cn) {
   int in, jn;
@@ -98,20 +111,20 @@ __device__ __forceinline__ bool nbr(int s, int e, int i, int j, const Geo& g, lo
     else if (e == 1) { in = i; jn = j; ok = true; }
     else { in = xp1(g, i); jn = j; ok = i < g.nx - 1 || g.px; }
   }
-  cn = ((long)(1 - s) * (g.ny + 2) + (jn + 1)) * g.nx + in;
+  cn = rowbase(g, 1 - s, jn) + in;
   return ok;
 }
 
 // offset (within a trace plane) and type of local edge e of cell (s,i,j)
 __device__ __forceinline__ long edge_off(int s, int e, int i, int j, const Geo& g, int& t) {
-  if (e == 0) { t = 0; return (long)(j + s + 1) * g.P + i; }
-  if (e == 1) { t = 2; return (long)(j + 1) * g.P + i; }
+  if (e == 0) { t = 0; return (long)(j + s + GHT) * g.P + i; }
+  if (e == 1) { t = 2; return (long)(j + GHT) * g.P + i; }
   t = 1;
-  return (long)(j + 1) * g.P + (s ? xp1(g, i) : i);
+  return (long)(j + GHT) * g.P + (s ? xp1(g, i) : i);
 }
 
 __device__ __forceinline__ long cidx(const Geo& g, int s, int j, int i) {
-  return ((long)s * (g.ny + 2) + (j + 1)) * g.nx + i;
+  return rowbase(g, s, j) + i;
 }
 
 // Addressing of cell vectors v[n*Nc + c]: buffer loads / stores with the vector's base in a scalar resource
@@ -404,8 +417,8 @@ __global__ __launch_bounds__(64 * HDG_LIFT_MFMA_WAVES) void k_edge_lift_mfma(Geo
   // (xcd band, row, shape) of this workgroup
   const int xcd_ = blockIdx.x & 7, q_ = blockIdx.x >> 3;
   const int jj_ = q_ >> 1, s = q_ & 1;
-  const int j = xcd_ * g.rows_xcd + jj_;
-  if (jj_ >= g.rows_xcd || j >= g.ny) return;  // whole workgroup
+  const int j = xcd_ * g.rows_xcd + jj_ - g.elo;
+  if (jj_ >= g.rows_xcd || j >= g.ny + g.ehi) return;  // whole workgroup
   const double* __restrict__ tsrc = s == 0 ? tabs0 : tabs1;
   for (int p = threadIdx.x; p < L::NTILES * 64; p += 64 * HDG_LIFT_MFMA_WAVES) tab[p] = tsrc[p];
   __syncthreads();
@@ -416,8 +429,8 @@ __global__ __launch_bounds__(64 * HDG_LIFT_MFMA_WAVES) void k_edge_lift_mfma(Geo
   const int gj = g.joff + j;
   const bool has0 = s == 0 ? gj > 0 : gj < g.nyg - 1;
   const int jn0 = s == 0 ? j - 1 : j + 1;
-  const long rowN0 = ((long)(1 - s) * (g.ny + 2) + (jn0 + 1)) * g.nx, rowN = ((long)(1 - s) * (g.ny + 2) + (j + 1)) * g.nx;
-  const long rowC = ((long)s * (g.ny + 2) + (j + 1)) * g.nx;
+  const long rowN0 = rowbase(g, 1 - s, jn0), rowN = rowbase(g, 1 - s, j);
+  const long rowC = rowbase(g, s, j);
   const int ntx = (g.nx + 15) >> 4;
   for (int tx = w; tx < ntx; tx += HDG_LIFT_MFMA_WAVES) {
     const int i = tx * 16 + li;
@@ -660,9 +673,9 @@ __global__ __launch_bounds__(128) void k_adv_apply2(Geo g, DevTables T, const do
   const int s = rem_ / nbx2;
   const int i = (rem_ - s * nbx2) * cpb + (threadIdx.x >> 1);
   const int a = threadIdx.x & 1;  // velocity component of this lane
-  const int j = xcd_ * g.rows_xcd + jj_;
-  if (jj_ >= g.rows_xcd || j >= g.ny || i >= g.nx) return;  // both lanes of a pair leave together
-  const long c = ((long)s * (g.ny + 2) + (j + 1)) * g.nx + i;
+  const int j = xcd_ * g.rows_xcd + jj_ - g.elo;
+  if (jj_ >= g.rows_xcd || j >= g.ny + g.ehi || i >= g.nx) return;  // both lanes of a pair leave together
+  const long c = rowbase(g, s, j) + i;
   // lane parity = component = the slot inside a mode's 16-byte pair: a lane pair reads one pair per mode
   const long cbase = (c << 1) + a;
   const long pstride = g.Nc << 1;  // doubles between consecutive modes
@@ -782,8 +795,8 @@ __global__ __launch_bounds__(512) void k_adv_mfma(Geo g, DevTables T, const doub
   __shared__ double slab[8][2][24][16];
   const int xcd_ = blockIdx.x & 7, q_ = blockIdx.x >> 3;
   const int jj_ = q_ >> 1, s = q_ & 1;
-  const int j = xcd_ * g.rows_xcd + jj_;
-  if (jj_ >= g.rows_xcd || j >= g.ny) return;  // whole workgroup
+  const int j = xcd_ * g.rows_xcd + jj_ - g.elo;
+  if (jj_ >= g.rows_xcd || j >= g.ny + g.ehi) return;  // whole workgroup
   const double* __restrict__ tsrc = s == 0 ? tabs0 : tabs1;
   for (int p = threadIdx.x; p < A::NTILES * 64; p += 512) tab[p] = tsrc[p];
   __syncthreads();
@@ -816,8 +829,8 @@ __global__ __launch_bounds__(512) void k_adv_mfma(Geo g, DevTables T, const doub
   const int gj = g.joff + j;
   const bool has0 = s == 0 ? gj > 0 : gj < g.nyg - 1;
   const int jn0 = s == 0 ? j - 1 : j + 1;
-  const long rowN0 = ((long)(1 - s) * (g.ny + 2) + (jn0 + 1)) * g.nx, rowN = ((long)(1 - s) * (g.ny + 2) + (j + 1)) * g.nx;
-  const long rowC = ((long)s * (g.ny + 2) + (j + 1)) * g.nx;
+  const long rowN0 = rowbase(g, 1 - s, jn0), rowN = rowbase(g, 1 - s, j);
+  const long rowC = rowbase(g, s, j);
   const int ntx = (g.nx + 15) >> 4;
   for (int tx = w; tx < ntx; tx += 8) {
     const int i = tx * 16 + li;
@@ -1081,13 +1094,13 @@ __global__ __launch_bounds__(128) void k_weak_div(Geo g, DevTables T, const doub
   const int xcd_ = blockIdx.x & 7, q_ = blockIdx.x >> 3;           \
   const int jj_ = q_ / g.nbxc;                                     \
   const int i = (q_ - jj_ * g.nbxc) * blockDim.x + threadIdx.x;    \
-  const int j = xcd_ * g.rows_xcdc + jj_;                          \
-  if (jj_ >= g.rows_xcdc || j >= g.nyc || i > g.nx - g.px) return; \
-  const long o = (long)(j + 1) * g.P + i;                          \
-  const bool in_x = i < g.nx, in_y = j < g.ny;                     \
+  const int j = xcd_ * g.rows_xcdc + jj_ - g.elo;                  \
+  if (jj_ >= g.rows_xcdc || j >= g.nyc + g.ehi || i > g.nx - g.px) return; \
+  const long o = (long)(j + GHT) * g.P + i;                        \
+  const bool in_x = i < g.nx, in_y = j < g.ny + g.ehi;  /* an extended launch only reaches rows that exist globally */ \
   const bool below = (g.joff + j) > 0;                             \
   const bool left = i > 0 || g.px;          /* a cell column to the left exists */ \
-  const long oL = (long)(j + 1) * g.P + xm1(g, i), oR = (long)(j + 1) * g.P + xp1(g, i); /* corners (i-1, j), (i+1, j) */ \
+  const long oL = (long)(j + GHT) * g.P + xm1(g, i), oR = (long)(j + GHT) * g.P + xp1(g, i); /* corners (i-1, j), (i+1, j) */ \
   (void)below; (void)left; (void)oL; (void)oR;
 
 template <int NL>
@@ -2429,50 +2442,55 @@ __global__ void k_trace_to_p1p(Geo g, int NL, const double* __restrict__ l, doub
 }
 // periodic strip on one rank: the ghost rows are the owned rows of the opposite side (array rows: 0 ghost below,
 // 1..ny owned, ny+1 ghost above)
-__global__ void k_wrap_rows(double* __restrict__ v, long plane_stride, int row_len, int nplanes, int ny) {
-  const long n = (long)nplanes * row_len;
+__global__ void k_wrap_rows(double* __restrict__ v, long plane_stride, int row_len, int nplanes, int ny, int gh) {
+  // array rows: gh ghost rows, ny owned rows (gh .. gh+ny-1), gh ghost rows; every ghost depth is filled
+  // (ny >= gh is checked by the engine)
+  const long n = (long)nplanes * row_len * gh;
   const long stride = (long)gridDim.x * blockDim.x;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += stride) {
-    const long pl = idx / row_len;
-    const int i = (int)(idx - pl * row_len);
+    const long pl = idx / (row_len * gh);
+    const int rem = (int)(idx - pl * row_len * gh);
+    const int d = rem / row_len, i = rem - d * row_len;
     double* p = v + pl * plane_stride;
-    p[i] = p[(long)ny * row_len + i];                       // below <- top owned row
-    p[(long)(ny + 1) * row_len + i] = p[(long)row_len + i];  // above <- bottom owned row
+    p[(long)d * row_len + i] = p[(long)(ny + d) * row_len + i];                  // below <- the top gh owned rows
+    p[(long)(gh + ny + d) * row_len + i] = p[(long)(gh + d) * row_len + i];      // above <- the bottom gh owned rows
   }
 }
 
 // ------------------------------------------------------------------------------------------
-// halo rows of the strip partition: pack the lowest / highest OWNED row of every plane into a
-// contiguous buffer, unpack received rows into the ghost rows.
-//   cell vectors:  planes = ndof * 2 shapes, row length nx,  row stride nx, plane stride (ny+2)*nx
-//   trace vectors: planes = 3 * NL,           row length P,   row stride P,  plane stride G
-// buf layout [plane][i]; `row` is the array row index (0 = ghost below, 1..ny owned, ny+1 ghost above)
+// halo rows of the strip partition: pack the lowest / highest `depth` OWNED rows of every plane into a
+// contiguous buffer, unpack received rows into the ghost rows next to the strip.
+//   cell vectors:  planes = ndof * 2 shapes, row length 2 nx (pairs), plane stride (ny+2GH)*2nx
+//   trace vectors: planes = 3 * NL,           row length P,           plane stride G
+// buf layout [plane][d][i]; rows are array row indices (gh-1 = first ghost below, gh..gh+ny-1 owned, gh+ny = first above;
+// gh = GH for cell arrays, GHT for trace arrays);
+// row_lo / row_hi = first row of the `depth` consecutive rows of the lower / upper message
 // ------------------------------------------------------------------------------------------
-// blockIdx.y = 0 / 1: lower / upper message, so one launch packs (unpacks) both halo rows
-__global__ void k_pack_rows(const double* __restrict__ v, long plane_stride, int row_len, int nplanes, int row_lo,
+// blockIdx.y = 0 / 1: lower / upper message, so one launch packs (unpacks) both halos
+__global__ void k_pack_rows(const double* __restrict__ v, long plane_stride, int row_len, int nplanes, int depth, int row_lo,
                             int row_hi, double* __restrict__ buf_lo, double* __restrict__ buf_hi) {
   const int row = blockIdx.y == 0 ? row_lo : row_hi;
   double* __restrict__ buf = blockIdx.y == 0 ? buf_lo : buf_hi;
-  const long n = (long)nplanes * row_len;
+  const long chunk = (long)depth * row_len;  // consecutive rows of a plane are contiguous
+  const long n = (long)nplanes * chunk;
   const long stride = (long)gridDim.x * blockDim.x;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += stride) {
-    const long pl = idx / row_len;
-    const int i = (int)(idx - pl * row_len);
-    buf[idx] = v[pl * plane_stride + (long)row * row_len + i];
+    const long pl = idx / chunk;
+    buf[idx] = v[pl * plane_stride + (long)row * row_len + (idx - pl * chunk)];
   }
 }
 // a negative row = that neighbour does not exist
-__global__ void k_unpack_rows(double* __restrict__ v, long plane_stride, int row_len, int nplanes, int row_lo,
+__global__ void k_unpack_rows(double* __restrict__ v, long plane_stride, int row_len, int nplanes, int depth, int row_lo,
                               int row_hi, const double* __restrict__ buf_lo, const double* __restrict__ buf_hi) {
   const int row = blockIdx.y == 0 ? row_lo : row_hi;
   if (row < 0) return;
   const double* __restrict__ buf = blockIdx.y == 0 ? buf_lo : buf_hi;
-  const long n = (long)nplanes * row_len;
+  const long chunk = (long)depth * row_len;
+  const long n = (long)nplanes * chunk;
   const long stride = (long)gridDim.x * blockDim.x;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += stride) {
-    const long pl = idx / row_len;
-    const int i = (int)(idx - pl * row_len);
-    v[pl * plane_stride + (long)row * row_len + i] = buf[idx];
+    const long pl = idx / chunk;
+    v[pl * plane_stride + (long)row * row_len + (idx - pl * chunk)] = buf[idx];
   }
 }
 
