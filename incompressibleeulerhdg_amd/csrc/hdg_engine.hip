@@ -68,6 +68,7 @@ struct Engine {
   bool periodic = false;  // doubly periodic square (hdg_config::periodic)
   double Ldom = 1.0;      // side of the square
   Geo g_all;           // same strip, but corner kernels visit every local row 0..ny (conversions)
+  double* cg_s = nullptr;  // s = T p of the single-reduction CG
   double *hb_slo = nullptr, *hb_shi = nullptr, *hb_rlo = nullptr, *hb_rhi = nullptr;  // halo buffers
   size_t cap_halo = 0;
   double* mg_gather = nullptr;
@@ -813,6 +814,12 @@ struct Engine {
         for (int q = 0; q < 4; q++) vl.p[q] = q < cnt ? V[off + q] : nullptr;
         if (big(n)) k_multidot<4, true><<<nb, HDG_DOT_BLOCK, 0, stream>>>(n, w, vl, cnt, d_part, mask_for(kind), cross ? 1 : 0);
         else k_multidot<4, false><<<nb, HDG_DOT_BLOCK, 0, stream>>>(n, w, vl, cnt, d_part, mask_for(kind), cross ? 1 : 0);
+      } else if (nout <= 6) {
+        // single-reduction CG: 4 vectors + 1 cross product
+        VecList<6> vl;
+        for (int q = 0; q < 6; q++) vl.p[q] = q < cnt ? V[off + q] : nullptr;
+        if (big(n)) k_multidot<6, true><<<nb, HDG_DOT_BLOCK, 0, stream>>>(n, w, vl, cnt, d_part, mask_for(kind), cross ? 1 : 0);
+        else k_multidot<6, false><<<nb, HDG_DOT_BLOCK, 0, stream>>>(n, w, vl, cnt, d_part, mask_for(kind), cross ? 1 : 0);
       } else {
         VecList<MAXV> vl;
         for (int q = 0; q < MAXV; q++) vl.p[q] = q < cnt ? V[off + q] : nullptr;
@@ -1613,10 +1620,61 @@ struct Engine {
       tf.set(cg_p, 0);
     }
   }
+  // The same iteration with ONE reduction (and one all-reduce on several ranks) per iteration instead of two
+  // (k_cg_sr_scalars): z = M r, w = T z, five inner products in one pass, then p, s = T p, x, r in one vector kernel.
+  // The update is queued before the host looks at the snapshot of (z',z'): when r_k turns out to be converged, x has
+  // already taken the step to x_{k+1}, which is harmless (a further CG step) and keeps the host off the critical path.
+  // Returns the number of iterations the convergence test needed (the extra step is not counted).
+  int trace_cg_sr(double* b, double* x, double rtol, int maxit, bool strict) {
+    project_const(b);
+    TraceFlowScope flow_(*this);
+    if (tf.Dx > 1) { halo_L(b, tf.Dx - 1); tf.set(b, tf.Dx - 1); }
+    trace_apply(x, b, 1.0, -1.0, cg_r);  // r = b - T x
+    if (tr_one_nn < 0) tr_one_nn = dot(NLv, tr_one, tr_one, KL);
+    if (!cg_s) cg_s = dalloc(NLv);
+    const int nvb = vec_blocks(NLv);
+    HIPCHECK(hipMemsetAsync(d_cgs, 0, sizeof(double) * 8, stream));
+    double norm0 = -1.0;
+    int its = 0;
+    while (true) {
+      trace_precond(cg_r, cg_z);
+      trace_apply(cg_z, nullptr, 0.0, 1.0, cg_Ap);  // w = T z
+      multidot(NLv, cg_z, {tr_one, cg_r, cg_z, cg_Ap}, nullptr, KL, true);  // (z,n), (z,r), (z,z), (z,w), (n,r) -> d_res
+      k_cg_sr_scalars<<<1, 1, 0, stream>>>(d_res, d_cgs, tr_one_nn, its == 0 ? 1 : 0);
+      HIPCHECK(hipMemcpyAsync(h_cgs, d_cgs, sizeof(double) * 8, hipMemcpyDeviceToHost, stream));
+      HIPCHECK(hipEventRecord(cg_ev, stream));
+      k_cg_sr_update<<<nvb, 256, 0, stream>>>(NLv, d_cgs, cg_z, tr_one, cg_Ap, cg_p, cg_s, x, cg_r);
+      tf.set(cg_s, its == 0 ? tf.get(cg_Ap) : std::min(tf.get(cg_s), tf.get(cg_Ap)));
+      tf.set(cg_r, std::min(tf.get(cg_r), tf.get(cg_s)));
+      tf.set(x, 0);
+      // snapshot of iteration `its` (cg_z is intact: the next preconditioner application has not been queued)
+      HIPCHECK(hipEventSynchronize(cg_ev));
+      if (h_cgs[6] == 1.0) throw NotConverged{"trace CG: breakdown (p.Ap <= 0)"};
+      double zz = h_cgs[4];
+      if (h_cgs[6] == 2.0) {  // z almost parallel to the null vector: measure the projected norm explicitly
+        axpby(NLv, -h_cgs[3], tr_one, 1.0, cg_z);
+        tf.set(cg_z, 0);
+        zz = dot(NLv, cg_z, cg_z, KL);
+        HIPCHECK(hipMemsetAsync(d_cgs + 6, 0, sizeof(double), stream));
+      }
+      if (!(zz == zz)) throw NotConverged{"trace CG: NaN residual"};
+      const double nrm = std::sqrt(std::max(zz, 0.0));
+      if (its == 0) { norm0 = nrm; if (norm0 == 0.0) return 0; }
+      if (debug_cg()) fprintf(stderr, "[cg] it %d |z|/|z0| %.3e  c %.3e rz %.3e\n", its, nrm / norm0, h_cgs[3], h_cgs[0]);
+      if (its > 0 && nrm <= rtol * norm0) return its;
+      if (its >= maxit) {
+        if (strict) throw NotConverged{"trace CG reached max iterations"};
+        return its;
+      }
+      its++;
+    }
+  }
   int trace_cg(double* b, double* x, double rtol = -1.0, int maxit = -1, bool strict = true) {
     if (rtol < 0) rtol = cfg.trace_rtol;
     if (maxit < 0) maxit = cfg.trace_maxit;
     static const bool host_scalars = std::getenv("HDG_CG_HOST_SCALARS") != nullptr;
+    static const bool two_red = std::getenv("HDG_CG_TWO_REDUCTIONS") != nullptr;
+    if (!host_scalars && !two_red) return trace_cg_sr(b, x, rtol, maxit, strict);
     if (!host_scalars) return trace_cg_dev(b, x, rtol, maxit, strict);
     project_const(b);
     trace_apply(x, b, 1.0, -1.0, cg_r);  // r = b - T x

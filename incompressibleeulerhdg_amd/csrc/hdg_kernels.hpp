@@ -1798,6 +1798,55 @@ __global__ void k_cg_p_dev(long N, const double* __restrict__ z, const double* _
                            double* __restrict__ p) {
   cg_p_body(N, z, nvec, sc[3], sc[2], p);
 }
+// Single-reduction form of the same preconditioned CG (Chronopoulos & Gear): with w = A z the step length follows
+// from (z',r) and (w,z) of ONE reduction, p.Ap = (w,z) - beta (z',r) / alpha_old, and s = A p is carried by the
+// recurrence s = w + beta s.  A n = 0 and A symmetric: (w, z') = (w, z) up to rounding.
+//   res = (z,n), (z,r), (z,z), (z,w), (n,r);  nn = (n,n);  sc[] as above
+// Zero residual (gamma = 0): alpha = beta = 0, the update is the identity and the host returns after the snapshot.
+__global__ void k_cg_sr_scalars(const double* __restrict__ res, double* __restrict__ sc, double nn, int first) {
+  const double c = res[0] / nn;
+  const double rzn = res[1] - c * res[4];
+  const double zz = res[2] - c * res[0];
+  if (!(zz > 1e-6 * res[2])) sc[6] = 2.0;
+  const double beta = first ? 0.0 : rzn / sc[0];
+  const double pAp = first ? res[3] : res[3] - beta * rzn / sc[1];
+  double alpha = rzn / pAp;
+  if (rzn == 0.0) alpha = 0.0;
+  else if (!(pAp > 0.0)) { sc[6] = 1.0; alpha = 0.0; }
+  sc[3] = c;
+  sc[4] = zz;
+  sc[7] = res[2];
+  sc[5] = pAp;
+  sc[2] = (rzn == 0.0) ? 0.0 : beta;
+  sc[1] = alpha;
+  sc[0] = rzn;
+}
+//   p = (z - c n) + beta p ;  s = w + beta s ;  x += alpha p ;  r -= alpha s       (one pass; whole arrays, ghost rows too)
+__global__ void k_cg_sr_update(long N, const double* __restrict__ sc, const double* __restrict__ z, const double* __restrict__ nvec,
+                               const double* __restrict__ w, double* __restrict__ p, double* __restrict__ s,
+                               double* __restrict__ x, double* __restrict__ r) {
+  const double alpha = sc[1], beta = sc[2], c = sc[3];
+  HDG_VEC_PROLOGUE
+  for (long i = tid_; i < NP2_; i += stride_) {
+    const hdg_d2 zp = fma2(-c, as2(nvec)[i], as2(z)[i]);
+    const hdg_d2 wv = as2(w)[i], xv = as2(x)[i], rv = as2(r)[i];
+    const hdg_d2 pv = (beta == 0.0) ? zp : fma2(beta, as2(p)[i], zp);
+    const hdg_d2 sv = (beta == 0.0) ? wv : fma2(beta, as2(s)[i], wv);
+    as2(p)[i] = pv;
+    as2(s)[i] = sv;
+    as2(x)[i] = fma2(alpha, pv, xv);
+    as2(r)[i] = fma2(-alpha, sv, rv);
+  }
+  if (tail_) {
+    const double zp = fma(-c, nvec[it_], z[it_]);
+    const double pv = (beta == 0.0) ? zp : fma(beta, p[it_], zp);
+    const double sv = (beta == 0.0) ? w[it_] : fma(beta, s[it_], w[it_]);
+    p[it_] = pv;
+    s[it_] = sv;
+    x[it_] = fma(alpha, pv, x[it_]);
+    r[it_] = fma(-alpha, sv, r[it_]);
+  }
+}
 // y = a*x + b*y
 template <bool NT>
 __global__ void k_axpby(long N, double a, const double* __restrict__ x, double b, double* __restrict__ y) {
