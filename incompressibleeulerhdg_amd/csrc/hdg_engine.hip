@@ -249,7 +249,7 @@ struct Engine {
     Ldom = c.length > 0 ? c.length : 1.0;
     if (periodic && comm->size > 1) throw std::string("the periodic mesh is implemented for a single rank");
     if (periodic && (c.nx % 2 != 0)) throw std::string("the periodic mesh needs an even nx (red-black coarse-grid sweeps)");
-    if (periodic && g.ny < GHT) throw std::string("the periodic mesh needs at least 4 cell rows");
+    if (periodic && g.ny < GH) throw std::string("the periodic mesh needs at least 4 cell rows");
     if (periodic) {
       // y-periodicity without touching a kernel: the strip pretends to lie in the middle of a taller mesh (no physical
       // boundary test in y fires, the top H row is a ghost copy of the bottom one like on a rank below another) and its
@@ -258,8 +258,19 @@ struct Engine {
     }
     g.px = periodic ? 1 : 0;
     g.P = ((c.nx + 1 + 15) / 16) * 16;
-    g.G = (long)(g.ny + 2 * GHT) * g.P;
-    g.Nc = 2L * c.nx * (g.ny + 2 * GH);
+    g.G = (long)(g.ny + 2 * GH) * g.P;
+    g.R = g.ny + 2 * GH;
+    if (std::getenv("HDG_ROW_PAD")) g.R += std::atoi(std::getenv("HDG_ROW_PAD"));
+    else {
+      // Padding rows: the element kernels stream 2 (k+2)(k+3)/2 dof planes at once, and on MI355X planes whose stride is
+      // close to a multiple of 2^15 B times 0, 1, 2, 4, 8 or 9 (mod 16) share memory channels.  Measured at C3, stride =
+      // R * 2^15 B (tools/padscan.sh, ms/step): R mod 16 = 8: 153, 9: 139.5, 4: 139.0, 2: 140; 3 .. 7 and 11 .. 15: 134.5 - 137.
+      for (int pad = 0; pad < 64; pad++) {
+        const double t = std::fmod((double)(2L * c.nx * (g.R + pad) * 16L), 524288.0) / 32768.0;
+        if ((t >= 2.5 && t <= 7.5) || (t >= 10.5 && t <= 15.5)) { g.R += pad; break; }
+      }
+    }
+    g.Nc = 2L * c.nx * g.R;
     g.elo = g.ehi = 0;
     g.h = Ldom / c.nx;
     g.nbx = (g.nx + bs() - 1) / bs();
@@ -362,7 +373,7 @@ struct Engine {
     hQ_dev = dalloc(NQb); hP_dev = dalloc(NPb);
     hL_dev = dalloc(NLb);
     {
-      long cap = std::max<long>(GH * 2L * NU * 2L * g.nx, GHT * 3L * NL * g.P);  // up to GH / GHT rows per message
+      long cap = std::max<long>(GH * 2L * NU * 2L * g.nx, GH * 3L * NL * g.P);  // up to GH / GH rows per message
       cap_halo = (size_t)cap;
       hb_slo = dalloc(cap); hb_shi = dalloc(cap); hb_rlo = dalloc(cap); hb_rhi = dalloc(cap);
     }
@@ -404,18 +415,78 @@ struct Engine {
     k_unpack_rows<<<dim3(nbh, 2), 256, 0, stream>>>(v, plane_stride, row_len, nplanes, depth, comm->rank > 0 ? gh - depth : -1,
                                                     comm->rank < comm->size - 1 ? gh + g.ny : -1, hb_rlo, hb_rhi);
   }
-  // velocity: component-pair layout -> a row of one (mode, shape) plane is 2 nx doubles.
-  // ghost_fresh: the vector whose first ghost rows the advection operator has just computed itself (adv_apply with
-  // extension): the next velocity exchange, if it is for that vector, is skipped.  One-shot: any other request clears it.
-  const double* ghost_fresh = nullptr;
-  void halo_Q(const double* v, int depth = 1) {
-    const bool skip = v == ghost_fresh && depth == 1;
-    ghost_fresh = nullptr;
-    if (skip) return;
-    halo_rows(const_cast<double*>(v), 2L * (g.ny + 2 * GH) * g.nx, 2 * g.nx, NU * 2, 0, depth);
+  // velocity: component-pair layout -> a row of one (mode, shape) plane is 2 nx doubles
+  void halo_Q(const double* v, int depth = 1) { halo_rows(const_cast<double*>(v), 2L * g.R * g.nx, 2 * g.nx, NU * 2, 0, depth); }
+  void halo_P(const double* v) { halo_rows(const_cast<double*>(v), (long)g.R * g.nx, g.nx, NP * 2, 1); }
+  void halo_L(const double* v, int depth = 1) { halo_rows(const_cast<double*>(v), g.G, g.P, 3 * NL, 2, depth); }
+
+  // ------------------------------------------------------------------ ghost-row bookkeeping of the solvers (strip partition)
+  // Inside a solver (FlowScope: tentative-velocity GMRES / Chebyshev, trace CG) every vector carries the number of ghost
+  // rows on which it currently holds the right values.  A row stencil (advection operator, edge lift, trace operator,
+  // fused smoother step) reads its input one row beyond the rows it computes: it is launched over as many ghost rows as
+  // its inputs allow (Geo::elo / ehi) and its result is valid there; pointwise kernels and the whole-array vector
+  // updates pass the validity of their inputs on.  Only a stencil input with NO valid ghost row triggers an exchange,
+  // fl.Dx rows deep.  Dx = GH = 4:
+  //   velocity: x_n exchanged -> b - A x_n on 3 ghost rows -> lift + Chebyshev step on 2 -> operator on 1 -> lift on 0:
+  //             one exchange per TWO iterations (the odd iterates stay valid on 2 rows, which the three-term step needs);
+  //   trace CG: z exchanged -> w = T z on 3 -> r on 3 -> pre-smoother 3 -> 2 -> coarse correction on 2 -> post-smoother
+  //             1 -> 0: one exchange per iteration.
+  // Redundant work: 6 row launches of operator + lift per two velocity iterations and side, 18 per CG iteration.
+  // Strips of 2-3 rows use Dx = ny; Dx = 1 (HDG_NO_EXT, periodic wrap, outside a FlowScope) is the classic exchange
+  // before every stencil.  A vector the bookkeeping has not seen counts as 0: the default is always the safe one.
+  struct Flow {
+    int nest = 0, Dx = 1;
+    std::vector<std::pair<const double*, int>> v;
+    bool active() const { return nest > 0; }
+    int get(const double* p) const {
+      if (nest > 0) for (const auto& e : v) if (e.first == p) return e.second;
+      return 0;
+    }
+    void set(const double* p, int d) {
+      if (nest == 0 || !p) return;
+      for (auto& e : v) if (e.first == p) { e.second = d; return; }
+      v.emplace_back(p, d);
+    }
+  } fl;
+  struct FlowScope {
+    Engine& E;
+    explicit FlowScope(Engine& e) : E(e) {
+      static const bool off = std::getenv("HDG_NO_EXT") != nullptr;
+      if (E.fl.nest++ == 0) {
+        E.fl.v.clear();
+        E.fl.Dx = (off || E.comm->size == 1 || E.periodic || !E.halo_on) ? 1 : std::min(GH, E.g.ny);
+      }
+    }
+    ~FlowScope() { if (--E.fl.nest == 0) E.fl.v.clear(); }
+  };
+  enum { FQ = 0, FP = 1, FL = 2 };
+  // input of a row stencil: at least one valid ghost row; returns the number of ghost rows the stencil may compute
+  int stencil_in(const double* in, int kind) {
+    const int depth = fl.active() ? fl.Dx : 1;
+    if (!fl.active() || fl.get(in) < 1) {
+      if (kind == FQ) halo_Q(in, depth); else if (kind == FP) halo_P(in); else halo_L(in, depth);
+      fl.set(in, kind == FP ? 1 : depth);
+    }
+    return fl.active() ? fl.get(in) - 1 : 0;
   }
-  void halo_P(const double* v) { halo_rows(const_cast<double*>(v), (long)(g.ny + 2 * GH) * g.nx, g.nx, NP * 2, 1); }
-  void halo_L(const double* v, int depth = 1) { halo_rows(const_cast<double*>(v), g.G, g.P, 3 * NL, 2, depth, GHT); }
+  // further input read on the computed rows only
+  int pw_in(const double* in, int ext) const { return in ? std::min(ext, fl.get(in)) : ext; }
+  // a vector that stays fixed through a solve (right-hand side, advecting velocity): valid on every row a stencil can reach
+  void flow_fixed_Q(const double* v) {
+    if (fl.active() && fl.Dx > 1 && fl.get(v) < fl.Dx - 1) { halo_Q(v, fl.Dx - 1); fl.set(v, fl.Dx - 1); }
+  }
+  Geo g_ext(int ext) const {  // this launch's geometry: ext ghost rows towards every existing neighbour
+    Geo c = g;
+    if (comm->size > 1 && ext > 0) {
+      c.elo = comm->rank > 0 ? ext : 0;
+      c.ehi = comm->rank < comm->size - 1 ? ext : 0;
+      c.rows_xcd = (c.ny + c.elo + c.ehi + 7) / 8;
+      c.rows_xcdc = (c.nyc + c.elo + c.ehi + 7) / 8;
+    }
+    return c;
+  }
+  dim3 cell_grid_of(const Geo& c) const { return dim3(8 * c.rows_xcd * 2 * c.nbx, 1, 1); }
+  static dim3 corner_grid_of(const Geo& c) { return dim3(8 * c.rows_xcdc * c.nbxc, 1, 1); }
 
   // ---- MFMA lift (k >= 3): tables in A-operand lane order for k_edge_lift_mfma.  Tile (mt, ks) of a matrix M:
   // 64 doubles, entry l = M[16 mt + l % 16][4 ks + l / 16] (zero outside M).  Order: W (2 M-tiles), N'_0..2, G.
@@ -511,76 +582,66 @@ struct Engine {
     static const bool off = std::getenv("HDG_NO_MFMA_LIFT") != nullptr;
     return !off && cfg.degree >= 3 && !periodic;  // the matrix-core kernels do not wrap column indices
   }
-  void lift_mfma(const double* t0, const double* t1, const double* in, double* out) {
-    const dim3 grid(8 * g.rows_xcd * 2);
+  void lift_mfma(const Geo& gx, const double* t0, const double* t1, const double* in, double* out) {
+    const dim3 grid(8 * gx.rows_xcd * 2);
     switch (cfg.degree) {
-      case 3: k_edge_lift_mfma<3><<<grid, 64 * HDG_LIFT_MFMA_WAVES, 0, stream>>>(g, t0, t1, in, out); break;
-      case 4: k_edge_lift_mfma<4><<<grid, 64 * HDG_LIFT_MFMA_WAVES, 0, stream>>>(g, t0, t1, in, out); break;
+      case 3: k_edge_lift_mfma<3><<<grid, 64 * HDG_LIFT_MFMA_WAVES, 0, stream>>>(gx, t0, t1, in, out); break;
+      case 4: k_edge_lift_mfma<4><<<grid, 64 * HDG_LIFT_MFMA_WAVES, 0, stream>>>(gx, t0, t1, in, out); break;
       default: throw std::string("MFMA lift: degree out of range");
     }
   }
   void bdm(const double* in, double* out) {
-    halo_Q(in);
+    const int ext = stencil_in(in, FQ);
+    const Geo gx = g_ext(ext);
+    fl.set(out, ext);
     if (use_mfma_lift()) {
       if (!liftm_plain[0])
         for (int sh = 0; sh < 2; sh++) liftm_plain[sh] = upload(pack_lift_mfma(sh, tab->Lift[sh]));
-      lift_mfma(liftm_plain[0], liftm_plain[1], in, out);
+      lift_mfma(gx, liftm_plain[0], liftm_plain[1], in, out);
       return;
     }
-    HDG_DISPATCH(k_edge_lift<KK, false, 0><<<cell_grid(), bs(), 0, stream>>>(g, dt, in, out, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, 0.0, nullptr));
+    HDG_DISPATCH(k_edge_lift<KK, false, 0><<<cell_grid_of(gx), bs(), 0, stream>>>(gx, dt, in, out, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, 0.0, nullptr));
+  }
+  // rows a lift with the optional Chebyshev epilogue may compute (chd_ = x_{n-1} -> x_{n+1}, chx_ = x_n)
+  int lift_ext(const double* in, const double* r, const double* chd_, const double* chx_, double c1) {
+    int ext = stencil_in(in, FQ);
+    ext = pw_in(r, ext);
+    if (chd_) { ext = pw_in(chx_, ext); if (c1 != 0.0) ext = pw_in(chd_, ext); }
+    return ext;
   }
   // out = Pi(in) + Dinv r   (second half of the two-level preconditioner, block-Jacobi fused in)
   void bdm_plus_bj(const double* in, double* out, const double* r, const double* D0, const double* D1,
                    double* chd_ = nullptr, double* chx_ = nullptr, double c1 = 0.0, double c2 = 0.0) {
-    halo_Q(in);
-    HDG_DISPATCH(k_edge_lift<KK, false, 1><<<cell_grid(), bs(), 0, stream>>>(g, dt, in, out, r, D0, D1, chd_, chx_, c1, c2, nullptr));
+    const int ext = lift_ext(in, r, chd_, chx_, c1);
+    const Geo gx = g_ext(ext);
+    HDG_DISPATCH(k_edge_lift<KK, false, 1><<<cell_grid_of(gx), bs(), 0, stream>>>(gx, dt, in, out, r, D0, D1, chd_, chx_, c1, c2, nullptr));
+    fl.set(out, ext); fl.set(chd_, ext);
   }
   // hybrid two-level preconditioner in ONE kernel: out = Pi(in) + Dinv (in - Pi(in)) = in + sum_e G_e d_e(in),
   // optionally fused with the Chebyshev step; G0 / G1: tables (I - Dinv_s) Lift_e of the stage (ensure_dinv)
   void bdm_hybrid(const double* in, double* out, const double* D0, const double* D1, double* chd_ = nullptr,
                   double* chx_ = nullptr, double c1 = 0.0, double c2 = 0.0, double* ss = nullptr) {
-    halo_Q(in);
+    const int ext = lift_ext(in, nullptr, chd_, chx_, c1);
+    const Geo gx = g_ext(ext);
+    fl.set(out, ext); fl.set(chd_, ext);
     if (use_mfma_lift() && out && !chd_ && !ss) {
       // GMRES path at k >= 3: no Chebyshev epilogue -> matrix-core kernel with the packed G tables of this stage
       for (size_t q = 0; q < hybg0.size(); q++)
-        if (hybg0[q] == D0) { lift_mfma(liftm_hyb0[q], liftm_hyb1[q], in, out); return; }
+        if (hybg0[q] == D0) { lift_mfma(gx, liftm_hyb0[q], liftm_hyb1[q], in, out); return; }
     }
-    HDG_DISPATCH(k_edge_lift<KK, false, 2><<<cell_grid(), bs(), 0, stream>>>(g, dt, in, out, nullptr, D0, D1, chd_, chx_, c1, c2, ss));
+    HDG_DISPATCH(k_edge_lift<KK, false, 2><<<cell_grid_of(gx), bs(), 0, stream>>>(gx, dt, in, out, nullptr, D0, D1, chd_, chx_, c1, c2, ss));
   }
   void bdm_T(const double* in, double* out) {
-    halo_Q(in);
-    HDG_DISPATCH(k_edge_lift<KK, true, 0><<<cell_grid(), bs(), 0, stream>>>(g, dt, in, out, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, 0.0, nullptr));
+    const int ext = stencil_in(in, FQ);
+    const Geo gx = g_ext(ext);
+    HDG_DISPATCH(k_edge_lift<KK, true, 0><<<cell_grid_of(gx), bs(), 0, stream>>>(gx, dt, in, out, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, 0.0, nullptr));
+    fl.set(out, ext);
   }
-  // Inside a tentative-velocity solve (ExtScope) on several ranks the operator also computes the FIRST GHOST ROWS of
-  // its result: x is exchanged two rows deep, Q* and b carry valid ghost rows for the whole solve (ExtScope), and the
-  // edge-lift preconditioner that consumes `out` next finds its neighbour values in place (ghost_fresh): one
-  // exchange per Krylov / Chebyshev iteration instead of two, for 2 / ny more rows of operator work.
-  bool solve_ext = false;
-  struct ExtScope {
-    Engine& E;
-    bool mine = false;
-    ExtScope(Engine& e, const double* qstar, const double* b) : E(e) {
-      static const bool off = std::getenv("HDG_NO_EXT") != nullptr;
-      if (off || E.solve_ext || E.comm->size == 1 || !E.halo_on || E.g.ny < GH) return;
-      E.halo_Q(qstar);
-      E.halo_Q(b);
-      E.solve_ext = mine = true;
-    }
-    ~ExtScope() { if (mine) { E.solve_ext = false; E.ghost_fresh = nullptr; } }
-  };
   void adv_apply(const double* x, const double* qstar, double* out, double gamma, const double* bsub = nullptr) {
-    const bool ext = solve_ext && halo_on;
-    Geo g = this->g;  // this launch's copy (row extension)
-    if (ext) {
-      g.elo = comm->rank > 0 ? 1 : 0;
-      g.ehi = comm->rank < comm->size - 1 ? 1 : 0;
-      g.rows_xcd = (g.ny + g.elo + g.ehi + 7) / 8;
-      halo_Q(x, 2);
-    } else {
-      halo_Q(x);
-    }
-    struct Fresh { Engine& E; const double* v; ~Fresh() { E.ghost_fresh = v; } } fresh_{*this, ext ? out : nullptr};
-    const dim3 cgrid(8 * g.rows_xcd * 2 * g.nbx, 1, 1);
+    const int ext = pw_in(bsub, pw_in(qstar, stencil_in(x, FQ)));
+    const Geo g = g_ext(ext);  // this launch's copy (row extension); shadows the member on purpose
+    fl.set(out, ext);
+    const dim3 cgrid = cell_grid_of(g);
     const double up = cfg.flux_upwind ? 1.0 : 0.0;
     // k >= 3: the whole operator on the matrix cores (k_adv_mfma); HDG_NO_MFMA_ADV falls back to the per-thread kernels
     static const bool no_mfma_adv = std::getenv("HDG_NO_MFMA_ADV") != nullptr;
@@ -610,6 +671,7 @@ struct Engine {
   }
   void blockdiag(const double* D0, const double* D1, const double* r, const double* zin, double cz, double* out) {
     HDG_DISPATCH(k_blockdiag<KK><<<cell_grid(), bs(), 0, stream>>>(g, D0, D1, r, zin, cz, out));
+    fl.set(out, 0);
   }
   void pgrad(const double* a, double ca, const double* b, double cb, const double* p, const double* l, double gamma,
              double* out) {
@@ -621,90 +683,38 @@ struct Engine {
     if (broken) { HDG_DISPATCH(k_weak_div<KK, true><<<cell_grid(), bs(), 0, stream>>>(g, dt, q, sc, out)); }
     else { HDG_DISPATCH(k_weak_div<KK, false><<<cell_grid(), bs(), 0, stream>>>(g, dt, q, sc, out)); }
   }
-  // ---- ghost-row bookkeeping of the trace solver (strip partition).  Inside the preconditioned CG (tf.active) every
-  // trace vector carries the number of ghost rows on which it currently holds the right values.  A row stencil
-  // (operator, fused smoother step) reads its input one row beyond the rows it computes: it is launched over as many
-  // ghost rows as its inputs allow (Geo::elo / ehi) and its result is valid there; only an input with no valid ghost
-  // row triggers an exchange, tf.Dx rows deep.  Dx = 4 = GHT: the direction vector p is the only exchange of a CG
-  // iteration (operator on 3 ghost rows, pre-smoother 3 -> 2, coarse correction on 2, post-smoother 1 -> 0); Dx = 2
-  // (strips of 2-3 rows): two; Dx = 1 (HDG_NO_EXT, periodic, outside the CG): the classic exchange before every
-  // stencil, five per iteration.  Redundant work at Dx = 4: 18 row launches per iteration and side.
-  struct TraceFlow {
-    bool active = false;
-    int Dx = 1;
-    std::vector<std::pair<const double*, int>> v;
-    int get(const double* p) const {
-      for (const auto& e : v) if (e.first == p) return e.second;
-      return 0;
-    }
-    void set(const double* p, int d) {
-      for (auto& e : v) if (e.first == p) { e.second = d; return; }
-      v.emplace_back(p, d);
-    }
-  } tf;
-  struct TraceFlowScope {
-    Engine& E;
-    explicit TraceFlowScope(Engine& e) : E(e) {
-      static const bool off = std::getenv("HDG_NO_EXT") != nullptr;
-      E.tf.v.clear();
-      E.tf.active = true;
-      E.tf.Dx = (off || E.comm->size == 1 || E.periodic || !E.halo_on) ? 1 : std::min(GHT, E.g.ny);
-    }
-    ~TraceFlowScope() { E.tf.active = false; E.tf.v.clear(); }
-  };
-  // input of a row stencil: make sure at least one ghost row is valid; returns the rows the stencil may extend over
-  int tr_stencil_input(const double* in) {
-    if (!tf.active) { halo_L(in); return 0; }
-    if (tf.get(in) < 1) { halo_L(in, tf.Dx); tf.set(in, tf.Dx); }
-    return tf.get(in) - 1;
-  }
-  int tr_pointwise_input(const double* in, int ext) const { return (in && tf.active) ? std::min(ext, tf.get(in)) : (in ? 0 : ext); }
-  Geo gtr(int ext) const {
-    Geo c = g;
-    if (comm->size > 1 && ext > 0) {
-      c.elo = comm->rank > 0 ? ext : 0;
-      c.ehi = comm->rank < comm->size - 1 ? ext : 0;
-      c.rows_xcdc = (c.nyc + c.elo + c.ehi + 7) / 8;
-    }
-    return c;
-  }
-  static dim3 corner_grid_of(const Geo& c) { return dim3(8 * c.rows_xcdc * c.nbxc, 1, 1); }
-  void trace_apply(const double* lam, const double* base, double cb, double ct, double* out, int max_ext = GHT) {
-    int ext = std::min(tr_stencil_input(lam), max_ext);
-    if (cb != 0.0) ext = tr_pointwise_input(base, ext);
-    const Geo c = gtr(ext);
+  void trace_apply(const double* lam, const double* base, double cb, double ct, double* out, int max_ext = GH) {
+    int ext = std::min(stencil_in(lam, FL), max_ext);
+    if (cb != 0.0) ext = pw_in(base, ext);
+    const Geo c = g_ext(ext);
     HDG_DISPATCH(k_trace_apply<KK><<<corner_grid_of(c), bs(), 0, stream>>>(c, pdt(), lam, base, cb, ct, out));
-    if (tf.active) tf.set(out, ext);
+    fl.set(out, ext);
   }
   // fused smoother step (k_trace_smooth): r = cb*base + ct*(-S) v, z = Dinv r, dn = c1 v + c2 z, optional outputs
   void trace_smooth(const double* v, const double* base, double cb, double ct, double c1, double c2, double* r_out,
                     double* d_out, double* x, bool xadd, double xv) {
-    int ext = tr_stencil_input(v);
-    if (cb != 0.0) ext = tr_pointwise_input(base, ext);
-    if (x && xadd) ext = tr_pointwise_input(x, ext);
-    const Geo c = gtr(ext);
+    int ext = stencil_in(v, FL);
+    if (cb != 0.0) ext = pw_in(base, ext);
+    if (x && xadd) ext = pw_in(x, ext);
+    const Geo c = g_ext(ext);
     HDG_DISPATCH(k_trace_smooth<KK><<<corner_grid_of(c), bs(), 0, stream>>>(c, pdt(), v, base, cb, ct, c1, c2, r_out, d_out, x,
                                                                          xadd ? 1 : 0, xv));
-    if (tf.active) {
-      if (r_out) tf.set(r_out, ext);
-      if (d_out) tf.set(d_out, ext);
-      if (x) tf.set(x, ext);
-    }
+    fl.set(r_out, ext); fl.set(d_out, ext); fl.set(x, ext);
   }
   void trace_cheb(const double* r, double* d, double* x, double c1, double c2, bool assign = false) {
-    int ext = tr_pointwise_input(r, GHT);
-    if (c1 != 0.0) ext = tr_pointwise_input(d, ext);
-    if (x && !assign) ext = tr_pointwise_input(x, ext);
-    const Geo c = gtr(ext);
+    int ext = pw_in(r, GH - 1);
+    if (c1 != 0.0) ext = pw_in(d, ext);
+    if (x && !assign) ext = pw_in(x, ext);
+    const Geo c = g_ext(ext);
     HDG_DISPATCH(k_trace_cheb<KK><<<corner_grid_of(c), bs(), 0, stream>>>(c, pdt(), r, d, x, c1, c2, assign ? 1 : 0));
-    if (tf.active) { tf.set(d, ext); if (x) tf.set(x, ext); }
+    fl.set(d, ext); fl.set(x, ext);
   }
   // z (+)= prolongation of the (replicated, global) vertex vector: pointwise, on every row on which z is valid
   void p1_to_trace(const double* xc, double* z, double accumulate) {
-    const int ext = accumulate != 0.0 ? tr_pointwise_input(z, GHT) : (tf.active ? tf.Dx : 0);
-    const Geo c = gtr(ext);
+    const int ext = accumulate != 0.0 ? pw_in(z, GH - 1) : (fl.active() ? fl.Dx - 1 : 0);
+    const Geo c = g_ext(ext);
     k_p1_to_trace<<<corner_grid_of(c), bs(), 0, stream>>>(c, NL, xc, z, accumulate, dt.elen[0], dt.elen[2], dt.elen[1]);
-    if (tf.active) tf.set(z, ext);
+    fl.set(z, ext);
   }
   void condense(const double* rw, const double* rp, const double* rl, double* out) {
     if (rw) halo_Q(rw);
@@ -750,21 +760,29 @@ struct Engine {
   void l_to_nodal(double* modal, double* nodal) { HDG_DISPATCH(k_l_convert<KK, false><<<corner_grid_all(), bs(), 0, stream>>>(g_all, dt, nodal, modal)); }
 
   // ------------------------------------------------------------------ vector helpers
+  // (whole arrays, ghost rows included: a result is valid on the ghost rows all its inputs are valid on -- fl)
   void copy(double* dst, const double* src, long n) {
     if (dst != src) HIPCHECK(hipMemcpyAsync(dst, src, sizeof(double) * n, hipMemcpyDeviceToDevice, stream));
+    fl.set(dst, fl.get(src));
   }
-  void zero(double* x, long n) { HIPCHECK(hipMemsetAsync(x, 0, sizeof(double) * n, stream)); }
+  void zero(double* x, long n) { HIPCHECK(hipMemsetAsync(x, 0, sizeof(double) * n, stream)); fl.set(x, GH); }
   void axpby(long n, double a, const double* x, double b, double* y) {
     if (big(n)) k_axpby<true><<<vec_blocks(n), 256, 0, stream>>>(n, a, x, b, y);
     else k_axpby<false><<<vec_blocks(n), 256, 0, stream>>>(n, a, x, b, y);
+    fl.set(y, b == 0.0 ? fl.get(x) : std::min(fl.get(x), fl.get(y)));
   }
   void cheb_update(double* pn, const double* z, const double* x, double c1, double c2) {
     if (big(NQ)) k_cheb_update<true><<<vec_blocks(NQ), 256, 0, stream>>>(NQ, pn, z, x, c1, c2);
     else k_cheb_update<false><<<vec_blocks(NQ), 256, 0, stream>>>(NQ, pn, z, x, c1, c2);
+    fl.set(pn, std::min(std::min(fl.get(z), fl.get(x)), c1 != 0.0 ? fl.get(pn) : GH));
   }
+  // out = scale * (w - sum_{l < nv} h_l V_l)   (V_l: the GMRES basis gm_V)
   void gs_update(const double* w, const Coefs& h, int nv, double scale, double* out) {
     if (big(NQ)) k_gs_update<MAXV, true><<<vec_blocks(NQ), 256, 0, stream>>>(NQ, w, d_gmV, h, nv, scale, out);
     else k_gs_update<MAXV, false><<<vec_blocks(NQ), 256, 0, stream>>>(NQ, w, d_gmV, h, nv, scale, out);
+    int d = fl.get(w);
+    for (int l = 0; l < nv; l++) d = std::min(d, fl.get(gm_V[l]));
+    fl.set(out, d);
   }
   void lincomb(long n, const std::vector<std::pair<const double*, double>>& terms, double* out) {
     // merge duplicate pointers, drop zeros, chunks of 8
@@ -787,15 +805,18 @@ struct Engine {
       else k_lincomb<false><<<vec_blocks(n), 256, 0, stream>>>(n, lc, out);
       first = false;
     }
+    int d = GH;
+    for (auto& q : t) d = std::min(d, fl.get(q.first));
+    fl.set(out, d);
   }
   // ownership mask for a vector of length n (cell-type or trace-type row structure)
   // row structure of a vector: cell-type (pressure, per-cell scalars), trace-type, velocity (component-pair layout:
   // a row of a plane holds 2 nx doubles)
   enum { KC = 1, KL = 2, KQ = 3 };
   RowMask mask_for(int kind) const {
-    if (kind == KL) return RowMask{g.P, g.ny + 2 * GHT, GHT, GHT + g.nyc - 1};
-    if (kind == KQ) return RowMask{2 * g.nx, g.ny + 2 * GH, GH, GH + g.ny - 1};
-    return RowMask{g.nx, g.ny + 2 * GH, GH, GH + g.ny - 1};
+    if (kind == KL) return RowMask{g.P, g.ny + 2 * GH, GH, GH + g.nyc - 1};
+    if (kind == KQ) return RowMask{2 * g.nx, g.R, GH, GH + g.ny - 1};
+    return RowMask{g.nx, g.R, GH, GH + g.ny - 1};
   }
   // dots of w against nv vectors over the OWNED entries, summed over ranks (host result); one sync
   // cross: res[nv] additionally receives (V[0], V[1]) from the same pass (nv >= 2, single chunk)
@@ -977,7 +998,9 @@ struct Engine {
   int gmres(const double* qstar, double gamma, int didx, const double* b, double* x, double rtol = -1.0,
             int maxit = -1, bool strict = true, std::vector<std::complex<double>>* ritz = nullptr, int m_cycle = 0,
             double* beta_first = nullptr, double* beta_last = nullptr, double beta0_given = -1.0) {
-    ExtScope ext_(*this, qstar, b);
+    FlowScope flow_(*this);
+    flow_fixed_Q(qstar);
+    flow_fixed_Q(b);
     const int m = std::min(std::max(1, cfg.gmres_restart), MAXV - 1);  // allocated basis / Hessenberg stride
     // adaptive cycle length: short cycles keep the Krylov-basis traffic low (the preconditioned operator
     // is benign: GMRES(4) needs 45.5 iterations where GMRES(30) needs 42.5 at C3); a cycle that reduces
@@ -1072,6 +1095,11 @@ struct Engine {
       for (int l = 0; l < j; l++) yc.c[l] = y[l];
       if (big(NQ)) k_basis_axpy<MAXV, true><<<nvb, 256, 0, stream>>>(NQ, x, d_gmV, yc, j);
       else k_basis_axpy<MAXV, false><<<nvb, 256, 0, stream>>>(NQ, x, d_gmV, yc, j);
+      {
+        int d = fl.get(x);
+        for (int l = 0; l < j; l++) d = std::min(d, fl.get(gm_V[l]));
+        fl.set(x, d);
+      }
       if (ritz) {
         // Ritz values: eigenvalues of the leading j x j block of the (unrotated) Hessenberg matrix
         std::vector<double> Hs((size_t)j * j);
@@ -1149,7 +1177,9 @@ struct Engine {
   std::vector<char> ch_slow;  // the last Chebyshev solve of the stage was slow: GMRES until the next re-estimate
   double* chd = nullptr;
   int cheb_gmres(const double* qstar, double gamma, int didx, const double* b, double* x) {
-    ExtScope ext_(*this, qstar, b);
+    FlowScope flow_(*this);
+    flow_fixed_Q(qstar);
+    flow_fixed_Q(b);
     const double rtol = cfg.tent_rtol;
     if ((int)ch_lmin.size() < s + 1) { ch_lmin.assign(s + 1, -1.0); ch_lmax.assign(s + 1, -1.0); }
     if (!chd) chd = dalloc(NQ);
@@ -1465,7 +1495,7 @@ struct Engine {
       k_trace_to_p1p<<<corner_grid(), bs(), 0, stream>>>(g, NL, wL2, mg_b[0], dt.elen[0], dt.elen[2], dt.elen[1]);
       run_vcycle();
       k_p1p_to_trace<<<corner_grid(), bs(), 0, stream>>>(g, NL, mg_x[0], z, 1.0, dt.elen[0], dt.elen[2], dt.elen[1]);
-      if (tf.active) tf.set(z, 0);  // owned rows only: the wrapped ghost rows are stale
+      fl.set(z, 0);  // owned rows only: the wrapped ghost rows are stale
       cheb_smooth(r, z, false, nsm);
       return;
     }
@@ -1561,8 +1591,8 @@ struct Engine {
   // after the preconditioner -- by then it has long arrived.  2 blocking syncs per iteration become 0.
   int trace_cg_dev(double* b, double* x, double rtol, int maxit, bool strict) {
     project_const(b);
-    TraceFlowScope flow_(*this);
-    if (tf.Dx > 1) { halo_L(b, tf.Dx - 1); tf.set(b, tf.Dx - 1); }  // r = b - T x on the ghost rows the operator reaches
+    FlowScope flow_(*this);
+    if (fl.Dx > 1) { halo_L(b, fl.Dx - 1); fl.set(b, fl.Dx - 1); }  // r = b - T x on the ghost rows the operator reaches
     trace_apply(x, b, 1.0, -1.0, cg_r);  // r = b - T x
     trace_precond(cg_r, cg_z);
     if (tr_one_nn < 0) tr_one_nn = dot(NLv, tr_one, tr_one, KL);
@@ -1582,7 +1612,7 @@ struct Engine {
       double zz = h_cgs[4];
       if (h_cgs[6] == 2.0) {
         axpby(NLv, -h_cgs[3], tr_one, 1.0, cg_z);
-        tf.set(cg_z, 0);
+        fl.set(cg_z, 0);
         zz = dot(NLv, cg_z, cg_z, KL);
         HIPCHECK(hipMemsetAsync(d_cgs + 6, 0, sizeof(double), stream));
         // the direction update that consumes this z has not been queued yet: it must not project a second time
@@ -1595,7 +1625,7 @@ struct Engine {
     const double norm0 = std::sqrt(std::max(snapshot_norm2(true), 0.0));
     if (norm0 == 0.0) return 0;
     k_cg_p_dev<<<nvb, 256, 0, stream>>>(NLv, cg_z, tr_one, d_cgs, cg_p);
-    tf.set(cg_p, 0);
+    fl.set(cg_p, 0);
     int its = 0;
     while (true) {
       trace_apply(cg_p, nullptr, 0.0, 1.0, cg_Ap);
@@ -1611,13 +1641,13 @@ struct Engine {
         }
       }
       k_cg_xr_dev<<<nvb, 256, 0, stream>>>(NLv, d_cgs, cg_p, cg_Ap, x, cg_r);  // whole arrays: ghost rows follow
-      tf.set(cg_r, std::min(tf.get(cg_r), tf.get(cg_Ap)));
-      tf.set(x, 0);
+      fl.set(cg_r, std::min(fl.get(cg_r), fl.get(cg_Ap)));
+      fl.set(x, 0);
       trace_precond(cg_r, cg_z);
       dots_and_snapshot(0);
       its++;
       k_cg_p_dev<<<nvb, 256, 0, stream>>>(NLv, cg_z, tr_one, d_cgs, cg_p);
-      tf.set(cg_p, 0);
+      fl.set(cg_p, 0);
     }
   }
   // The same iteration with ONE reduction (and one all-reduce on several ranks) per iteration instead of two
@@ -1627,8 +1657,8 @@ struct Engine {
   // Returns the number of iterations the convergence test needed (the extra step is not counted).
   int trace_cg_sr(double* b, double* x, double rtol, int maxit, bool strict) {
     project_const(b);
-    TraceFlowScope flow_(*this);
-    if (tf.Dx > 1) { halo_L(b, tf.Dx - 1); tf.set(b, tf.Dx - 1); }
+    FlowScope flow_(*this);
+    if (fl.Dx > 1) { halo_L(b, fl.Dx - 1); fl.set(b, fl.Dx - 1); }
     trace_apply(x, b, 1.0, -1.0, cg_r);  // r = b - T x
     if (tr_one_nn < 0) tr_one_nn = dot(NLv, tr_one, tr_one, KL);
     if (!cg_s) cg_s = dalloc(NLv);
@@ -1644,16 +1674,16 @@ struct Engine {
       HIPCHECK(hipMemcpyAsync(h_cgs, d_cgs, sizeof(double) * 8, hipMemcpyDeviceToHost, stream));
       HIPCHECK(hipEventRecord(cg_ev, stream));
       k_cg_sr_update<<<nvb, 256, 0, stream>>>(NLv, d_cgs, cg_z, tr_one, cg_Ap, cg_p, cg_s, x, cg_r);
-      tf.set(cg_s, its == 0 ? tf.get(cg_Ap) : std::min(tf.get(cg_s), tf.get(cg_Ap)));
-      tf.set(cg_r, std::min(tf.get(cg_r), tf.get(cg_s)));
-      tf.set(x, 0);
+      fl.set(cg_s, its == 0 ? fl.get(cg_Ap) : std::min(fl.get(cg_s), fl.get(cg_Ap)));
+      fl.set(cg_r, std::min(fl.get(cg_r), fl.get(cg_s)));
+      fl.set(x, 0);
       // snapshot of iteration `its` (cg_z is intact: the next preconditioner application has not been queued)
       HIPCHECK(hipEventSynchronize(cg_ev));
       if (h_cgs[6] == 1.0) throw NotConverged{"trace CG: breakdown (p.Ap <= 0)"};
       double zz = h_cgs[4];
       if (h_cgs[6] == 2.0) {  // z almost parallel to the null vector: measure the projected norm explicitly
         axpby(NLv, -h_cgs[3], tr_one, 1.0, cg_z);
-        tf.set(cg_z, 0);
+        fl.set(cg_z, 0);
         zz = dot(NLv, cg_z, cg_z, KL);
         HIPCHECK(hipMemsetAsync(d_cgs + 6, 0, sizeof(double), stream));
       }
@@ -2413,7 +2443,7 @@ static int create_impl(const hdg_config* cfg, int rank, int nranks, int backend,
       const int k = cfg->degree;
       const size_t nu = (size_t)(k + 2) * (k + 3) / 2;
       const size_t P = ((size_t)cfg->nx + 1 + 15) / 16 * 16;
-      const size_t cap_halo = std::max<size_t>(hdg::GH * 2 * nu * 2 * cfg->nx, hdg::GHT * 3 * (size_t)(k + 1) * P);
+      const size_t cap_halo = std::max<size_t>(hdg::GH * 2 * nu * 2 * cfg->nx, hdg::GH * 3 * (size_t)(k + 1) * P);
       const size_t cap_gather = ((size_t)cfg->ny / nranks + 1) * ((size_t)cfg->nx + 1);
       comm.reset(new hdg::CommShm(rank, nranks, token, cap_halo, cap_gather));
     } else return HDG_ERR_ARG;

@@ -24,22 +24,23 @@ namespace hdg {
 
 struct Geo {
   // Strip partition: a rank owns the cell rows joff .. joff+ny-1 of the global
-  // nx x nyg mesh.  Cell arrays carry GH = 2 GHOST rows below (j = -2, -1) and above (j = ny, ny+1), trace arrays GHT = 4:
-  //   cell index   c = (s*(ny+2GH) + (j+GH))*nx + i       j in [-GH, ny+GH-1]
-  //   trace offset o = (j+GHT)*P + i                       corner rows j in [-GHT, ny+GHT-1]
-  // Depth 1 serves every stencil operator; depth 2 of a velocity vector lets the advection operator compute its
-  // result on the first ghost rows as well (elo / ehi below), so that the edge-lift preconditioner that follows
-  // needs no exchange of its own: one exchange per Krylov / Chebyshev iteration instead of two.  The trace rows are
-  // deeper because one preconditioned CG iteration chains five row stencils (operator, two smoother steps before and
-  // after the coarse correction): with the direction vector exchanged four rows deep every one of them can run on
-  // rows whose inputs are still valid (Engine::TraceFlow), one exchange per CG iteration instead of five.
+  // nx x nyg mesh.  Every array carries GH = 4 GHOST rows below (j = -4 .. -1) and above (j = ny .. ny+3):
+  //   cell index   c = (s*R + (j+GH))*nx + i              j in [-GH, ny+GH-1];  R >= ny+2GH rows per shape plane
+  //   trace offset o = (j+GH)*P + i                        corner rows j in [-GH, ny+GH-1]
+  // Depth 1 serves one row stencil.  The solvers chain stencils: a Chebyshev / GMRES iteration of the tentative
+  // velocity is advection operator + edge lift (2), a preconditioned CG iteration of the trace system operator + two
+  // smoother steps before and after the coarse correction (5).  With an input exchanged GH rows deep each stencil of
+  // the chain runs on as many ghost rows as its inputs are still valid on (elo / ehi below, Engine::Flow) and its
+  // result is valid there: one exchange per two velocity iterations and one per CG iteration instead of 4 and 5.
   // A rank computes the corner rows 0 .. nyc-1 (nyc = ny, or ny+1 on the topmost rank which also
   // owns the edges on the top boundary); row ny of the other ranks is a ghost copy of the upper
   // neighbour's row 0.  With one rank the ghost rows exist but are never referenced.
   int nx, ny, P;
   int nyg, joff, nyc;
-  long G;   // (ny+2GHT)*P : one trace plane
-  long Nc;  // 2*nx*(ny+2GH): stride between dof planes of a cell vector
+  long G;   // (ny+2GH)*P : one trace plane
+  long Nc;  // 2*nx*R: stride between dof planes of a cell vector
+  int R;    // rows per shape plane of a cell array: ny + 2GH, plus padding rows that keep the plane stride away from
+            // large powers of two (C3 with GH = 4: 2 R = 16 * 129 rows -> stride 2^18 * 129 B, advection + lift 25 % slower)
   double h;
   // XCD-aware block mapping (1-D grids): workgroups are dealt round-robin over the 8 XCDs, so
   // blockIdx % 8 labels the XCD.  Each XCD owns a contiguous band of mesh rows and walks it row by
@@ -56,14 +57,12 @@ struct Geo {
   //      nyg = 3 ny: every physical-boundary test in y is false) and fills the ghost rows from the opposite side of
   //      the strip before every stencil operator, exactly as it would from a neighbouring rank.
   int px;
-  // THIS launch also computes elo ghost rows below and ehi above the owned rows (rows_xcd / rows_xcdc of the copy
-  // cover the extended range).  Cell kernels: only the advection operator (Engine::adv_apply, 0 or 1); corner kernels:
-  // the operators of the trace solver (Engine::TraceFlow, up to GHT - 1).
+  // THIS launch also computes elo ghost rows below and ehi above the owned rows (at most GH - 1; rows_xcd / rows_xcdc
+  // of the copy cover the extended range): the stencil operators of the two solvers (Engine::Flow).
   int elo, ehi;
 };
-constexpr int GH = 2;   // ghost rows on either side of the strip in every cell / pressure array
-constexpr int GHT = 4;  // ... and in every trace array
-__device__ __forceinline__ long rowbase(const Geo& g, int s, int j) { return ((long)s * (g.ny + 2 * GH) + (j + GH)) * g.nx; }
+constexpr int GH = 4;  // ghost rows on either side of the strip in every cell / pressure / trace array
+__device__ __forceinline__ long rowbase(const Geo& g, int s, int j) { return ((long)s * g.R + (j + GH)) * g.nx; }
 __device__ __forceinline__ int xm1(const Geo& g, int i) { return i > 0 ? i - 1 : g.nx - 1; }       // column to the left
 __device__ __forceinline__ int xp1(const Geo& g, int i) { return (g.px && i == g.nx - 1) ? 0 : i + 1; }  // column to the right
 
@@ -117,10 +116,10 @@ __device__ __forceinline__ bool nbr(int s, int e, int i, int j, const Geo& g, lo
 
 // offset (within a trace plane) and type of local edge e of cell (s,i,j)
 __device__ __forceinline__ long edge_off(int s, int e, int i, int j, const Geo& g, int& t) {
-  if (e == 0) { t = 0; return (long)(j + s + GHT) * g.P + i; }
-  if (e == 1) { t = 2; return (long)(j + GHT) * g.P + i; }
+  if (e == 0) { t = 0; return (long)(j + s + GH) * g.P + i; }
+  if (e == 1) { t = 2; return (long)(j + GH) * g.P + i; }
   t = 1;
-  return (long)(j + GHT) * g.P + (s ? xp1(g, i) : i);
+  return (long)(j + GH) * g.P + (s ? xp1(g, i) : i);
 }
 
 __device__ __forceinline__ long cidx(const Geo& g, int s, int j, int i) {
@@ -1096,11 +1095,11 @@ __global__ __launch_bounds__(128) void k_weak_div(Geo g, DevTables T, const doub
   const int i = (q_ - jj_ * g.nbxc) * blockDim.x + threadIdx.x;    \
   const int j = xcd_ * g.rows_xcdc + jj_ - g.elo;                  \
   if (jj_ >= g.rows_xcdc || j >= g.nyc + g.ehi || i > g.nx - g.px) return; \
-  const long o = (long)(j + GHT) * g.P + i;                        \
+  const long o = (long)(j + GH) * g.P + i;                        \
   const bool in_x = i < g.nx, in_y = j < g.ny + g.ehi;  /* an extended launch only reaches rows that exist globally */ \
   const bool below = (g.joff + j) > 0;                             \
   const bool left = i > 0 || g.px;          /* a cell column to the left exists */ \
-  const long oL = (long)(j + GHT) * g.P + xm1(g, i), oR = (long)(j + GHT) * g.P + xp1(g, i); /* corners (i-1, j), (i+1, j) */ \
+  const long oL = (long)(j + GH) * g.P + xm1(g, i), oR = (long)(j + GH) * g.P + xp1(g, i); /* corners (i-1, j), (i+1, j) */ \
   (void)below; (void)left; (void)oL; (void)oR;
 
 template <int NL>
@@ -2511,8 +2510,7 @@ __global__ void k_wrap_rows(double* __restrict__ v, long plane_stride, int row_l
 // contiguous buffer, unpack received rows into the ghost rows next to the strip.
 //   cell vectors:  planes = ndof * 2 shapes, row length 2 nx (pairs), plane stride (ny+2GH)*2nx
 //   trace vectors: planes = 3 * NL,           row length P,           plane stride G
-// buf layout [plane][d][i]; rows are array row indices (gh-1 = first ghost below, gh..gh+ny-1 owned, gh+ny = first above;
-// gh = GH for cell arrays, GHT for trace arrays);
+// buf layout [plane][d][i]; rows are array row indices (gh-1 = first ghost below, gh..gh+ny-1 owned, gh+ny = first above);
 // row_lo / row_hi = first row of the `depth` consecutive rows of the lower / upper message
 // ------------------------------------------------------------------------------------------
 // blockIdx.y = 0 / 1: lower / upper message, so one launch packs (unpacks) both halos
