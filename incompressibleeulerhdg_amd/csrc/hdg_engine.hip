@@ -1454,6 +1454,49 @@ struct Engine {
     p1_smooth(lev, nsw, true);
   }
   void run_vcycle() { if (periodic) vcycle_periodic(0); else vcycle(0); }
+  // ---- strip partition: the finest vertex grid stays distributed, the rest of the V-cycle is replicated.
+  // The replicated cycle (every rank gathers the whole (nx+1)^2 right-hand side, 8.4 MB at C3, and runs every level)
+  // does not shrink with the number of ranks.  Here each rank keeps its ny+1 vertex rows of level 0:
+  //   1 exchange of 40 vertex rows + the partial cut rows with the strip neighbours (contiguous rows, no packing),
+  //   down leg (smoother, residual, restriction) on the tile rows that reach the strip -- the fused leg kernels work on
+  //     32-row tiles with recomputed halos, so one extra tile row on either side makes x_pre and the coarse right-hand
+  //     side right on everything the up leg and the neighbours' overlap need,
+  //   all-gather of the LEVEL-1 right-hand side (a quarter of the bytes), levels >= 1 replicated as before,
+  //   up leg on the same tile rows: x_0 on the strip and the 3 rows around it that the prolongation to the trace
+  //   ghost rows reads.
+  // Needs ny a multiple of 32 and >= 64 (C3 on 8 ranks: 128); otherwise the replicated cycle is used.
+  static constexpr int MG_HALO = 40;
+  bool mg_distributed() const {
+    static const bool off = std::getenv("HDG_MG_REPLICATED") != nullptr;
+    static const bool fuse_legs = !std::getenv("HDG_MG_NO_FUSE");
+    static const int nsw = std::getenv("HDG_MG_SWEEPS") ? std::atoi(std::getenv("HDG_MG_SWEEPS")) : 2;
+    return !off && fuse_legs && nsw == 2 && mg_gather && comm->size > 1 && !periodic && halo_on && mg_n.size() >= 2 &&
+           mg_n[0] > 32 && (g.ny % HDG_P1_TS) == 0 && g.ny >= 2 * HDG_P1_TS && (g.nx & 1) == 0 &&
+           (size_t)(MG_HALO + 1) * (g.nx + 1) <= cap_halo;
+  }
+  void vcycle_distributed_top() {
+    const int n = mg_n[0], st = n + 1, J0 = g.joff, J1 = g.joff + g.ny;
+    const bool has_lo = comm->rank > 0, has_hi = comm->rank < comm->size - 1;
+    // halo of the level-0 right-hand side: lower message = rows J0 .. J0+40 (partial cut row first), upper = rows J1-40 .. J1
+    const size_t nmsg = (size_t)(MG_HALO + 1) * st;
+    comm->exchange(mg_b[0] + (long)J0 * st, hb_rlo, mg_b[0] + (long)(J1 - MG_HALO) * st, hb_rhi, nmsg, stream);
+    n_halo[1]++;
+    k_p1_merge_halo<<<std::min(vec_blocks((long)nmsg), 256), 256, 0, stream>>>(st, MG_HALO, J0, J1, has_lo ? 1 : 0, has_hi ? 1 : 0,
+                                                                             hb_rlo, hb_rhi, mg_b[0]);
+    // tile rows of this rank (+ one on either side where a neighbour exists)
+    const int nt = (n + 1 + HDG_P1_TS - 1) / HDG_P1_TS;
+    const int t0 = std::max(0, J0 / HDG_P1_TS - (has_lo ? 1 : 0));
+    const int t1 = std::min(nt, J1 / HDG_P1_TS + 1);  // incl. the tile row that holds vertex row J1 (the top rank: row n)
+    const dim3 gt(nt, t1 - t0);
+    k_p1_down<2><<<gt, HDG_P1_THREADS, 0, stream>>>(n, mg_b[0], mg_r[0], mg_b[1], t0);
+    // level-1 right-hand side: every rank contributes its ny/2 + 1 coarse rows (the cut rows are computed twice, identically)
+    const int nc = mg_n[1], stc = nc + 1, nyc2 = g.ny / 2;
+    comm->allgather(mg_b[1] + (long)(J0 / 2) * stc, mg_gather, (size_t)(nyc2 + 1) * stc, stream);
+    n_gather++;
+    k_p1_assemble<<<vec_blocks((long)stc * stc), 256, 0, stream>>>(comm->size, nyc2, stc, mg_gather, mg_b[1], 0);
+    vcycle(1);
+    k_p1_up<2><<<gt, HDG_P1_THREADS, 0, stream>>>(n, mg_x[1], mg_b[0], mg_r[0], mg_x[0], t0);
+  }
   // the same V(2,2) cycle on the periodic vertex grids (per-level kernels)
   void vcycle_periodic(int lev) {
     const int n = mg_n[lev];
@@ -1500,6 +1543,12 @@ struct Engine {
       return;
     }
     k_trace_to_p1<<<corner_grid_all(), bs(), 0, stream>>>(g_all, NL, wL2, mg_b[0], dt.elen[0], dt.elen[2], dt.elen[1], partial);
+    if (mg_distributed()) {
+      vcycle_distributed_top();
+      p1_to_trace(mg_x[0], z, 1.0);
+      cheb_smooth(r, z, false, nsm);
+      return;
+    }
     if (mg_gather) {
       // every rank contributes its (ny+1) vertex rows; one kernel assembles the global vector from the blocks
       const long blk = (long)(g.ny + 1) * (g.nx + 1);

@@ -2168,12 +2168,12 @@ __device__ __forceinline__ void p1_tile_sweeps(double* X, const double* B, int n
 // down leg: x = 0, nsw sweeps on A x = b, r = b - A x, bc = R r (coarse right-hand side); x is stored to xpre
 template <int NSW>
 __global__ __launch_bounds__(HDG_P1_THREADS) void k_p1_down(int n, const double* __restrict__ b, double* __restrict__ xpre,
-                                                            double* __restrict__ bc) {
+                                                            double* __restrict__ bc, int jt0 = 0) {
   constexpr int H = 2 * NSW + 2, W = HDG_P1_TS + 2 * H;
   __shared__ double X[W * W];
   __shared__ double B[W * W];
   const int st = n + 1;
-  const int i0 = blockIdx.x * HDG_P1_TS, j0 = blockIdx.y * HDG_P1_TS, gi0 = i0 - H, gj0 = j0 - H;
+  const int i0 = blockIdx.x * HDG_P1_TS, j0 = (blockIdx.y + jt0) * HDG_P1_TS, gi0 = i0 - H, gj0 = j0 - H;  // jt0: first tile row of this launch
   for (int p = threadIdx.x; p < W * W; p += HDG_P1_THREADS) {
     const int lj = p / W, li = p - lj * W, gi = gi0 + li, gj = gj0 + lj;
     const bool in = gi >= 0 && gj >= 0 && gi <= n && gj <= n;
@@ -2217,12 +2217,12 @@ __global__ __launch_bounds__(HDG_P1_THREADS) void k_p1_down(int n, const double*
 // DIFFERENT buffers: a workgroup reads the halo of its tile while its neighbours store theirs.
 template <int NSW>
 __global__ __launch_bounds__(HDG_P1_THREADS) void k_p1_up(int n, const double* __restrict__ xc, const double* __restrict__ b,
-                                                          const double* __restrict__ xpre, double* __restrict__ x) {
+                                                          const double* __restrict__ xpre, double* __restrict__ x, int jt0 = 0) {
   constexpr int H = 2 * NSW, W = HDG_P1_TS + 2 * H;
   __shared__ double X[W * W];
   __shared__ double B[W * W];
   const int st = n + 1, nc = n >> 1, sc = nc + 1;
-  const int i0 = blockIdx.x * HDG_P1_TS, j0 = blockIdx.y * HDG_P1_TS, gi0 = i0 - H, gj0 = j0 - H;
+  const int i0 = blockIdx.x * HDG_P1_TS, j0 = (blockIdx.y + jt0) * HDG_P1_TS, gi0 = i0 - H, gj0 = j0 - H;  // jt0: first tile row of this launch
   for (int p = threadIdx.x; p < W * W; p += HDG_P1_THREADS) {
     const int lj = p / W, li = p - lj * W, i = gi0 + li, j = gj0 + lj;
     if (i < 0 || j < 0 || i > n || j > n) { X[p] = 0.0; B[p] = 0.0; continue; }
@@ -2402,6 +2402,26 @@ __global__ void k_trace_to_p1(Geo g, int NL, const double* __restrict__ l, doubl
   if (!extra && i > 0 && in_y) acc += sD * (D0[o - 1] - r3 * D1[o - 1]);       // D(i-1,j): a-end (x_i,y_j)
   if (i < g.nx && from_below) acc += sD * (D0[o - g.P] + r3 * D1[o - g.P]);    // D(i,j-1): b-end (x_i,y_j)
   rc[(long)(g.joff + j) * st + i] = acc;
+}
+// Distributed finest level of the vertex-grid V-cycle (strip partition): after the restriction from the rank's own edges
+// the neighbours swap `depth` vertex rows next to the cut plus their PARTIAL sums of the cut row itself.  A message holds
+// depth + 1 rows of st values; from_lo = [rows J0-depth .. J0-1, partial row J0], from_hi = [partial row J1, rows J1+1 ..
+// J1+depth] (J0 / J1: the rank's lowest / highest vertex row).  The partial rows are added, the others stored.
+__global__ void k_p1_merge_halo(int st, int depth, int J0, int J1, int has_lo, int has_hi, const double* __restrict__ from_lo,
+                                const double* __restrict__ from_hi, double* __restrict__ b) {
+  const long n = (long)(depth + 1) * st;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += stride) {
+    const int row = (int)(idx / st), i = (int)(idx - (long)row * st);
+    if (has_lo) {
+      if (row < depth) b[(long)(J0 - depth + row) * st + i] = from_lo[idx];
+      else b[(long)J0 * st + i] += from_lo[idx];
+    }
+    if (has_hi) {
+      if (row == 0) b[(long)J1 * st + i] += from_hi[idx];
+      else b[(long)(J1 + row) * st + i] = from_hi[idx];
+    }
+  }
 }
 // global vertex vector from the all-gathered blocks of (ny+1) rows per rank, in ONE launch: rank r owns the rows
 // r*ny .. (r+1)*ny-1 (the last rank also the top row); on a cut the lower rank's extra row is added (partial sums)

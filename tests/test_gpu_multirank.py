@@ -58,7 +58,7 @@ def _assemble(parts, k, nx):
     return Q, p, lam
 
 
-@pytest.mark.parametrize("nranks,k,nx", [(2, 1, 8), (2, 2, 8), (4, 1, 8), (3, 2, 6), (2, 1, 6), (2, 3, 4), (2, 2, 96), (2, 3, 40), (4, 4, 24)])
+@pytest.mark.parametrize("nranks,k,nx", [(2, 1, 8), (2, 2, 8), (4, 1, 8), (3, 2, 6), (2, 1, 6), (2, 3, 4), (2, 2, 96), (2, 3, 40), (4, 4, 24), (2, 1, 128), (4, 2, 256)])
 def test_strip_partition_matches_single_rank(hip_lib, tmp_path, nranks, k, nx):
     from incompressibleeulerhdg_amd import _lib
     from incompressibleeulerhdg_amd.mesh import UnitSquareMesh
