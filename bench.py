@@ -203,13 +203,16 @@ def cpu_baseline(degree, nx_sample=None):
     t.set_forcing_profile(Qs)
     t.run_separable(ssp2_scales(1, dt, kappa))  # warm-up step (mirrors --warmup, driver.py:157-162)
     t.iteration_stats(reset=True)
+    t.timers(reset=True)
     nsteps = 2
     t0 = time.perf_counter()
     t.run_separable(ssp2_scales(nsteps, dt, kappa, t0=dt))
     el = time.perf_counter() - t0
     sums, cnt = t.iteration_stats()
     its = [float(a / max(b, 1)) for a, b in zip(sums, cnt)]
-    return dict(value=t.n_total * nsteps / el / 1e6, unit="million DOF-updates/s", cores=t.threads, kind="port",
+    # the reference's PerformanceLog labels (logging.py:34-60), as for the GPU run's `timers`
+    tm = {lab: {"ncall": n, "total_ms": 1e3 * sec, "avg_ms": 1e3 * sec / max(n, 1)} for lab, (sec, n) in t.timers().items()}
+    return dict(value=t.n_total * nsteps / el / 1e6, unit="million DOF-updates/s", cores=t.threads, kind="port", timers=tm,
                 sample=f"C++/OpenMP twin (oracle/cpu_twin), HDG-IMEX SSP2(3,3,2) R=2 upwind k={degree} nx={nx} "
                        f"({t.n_total} unknowns), {t.threads} threads, 1 warm-up + {nsteps} timed steps in {el:.1f} s; "
                        f"Krylov iterations tentative/pressure {its[0]:.1f}/{its[1]:.1f} (GMRES(8) / PCG)")

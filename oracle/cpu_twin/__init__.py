@@ -158,6 +158,14 @@ class CpuTwin:
         self._ck(self.lib.hdgcpu_get_iteration_stats(self.h, _p(sums), cnt.ctypes.data_as(C.POINTER(C.c_long)), C.c_int(1 if reset else 0)))
         return sums, cnt
 
+    TIMER_LABELS = ("timestep", "bdm_projection", "tentative_velocity_solve", "pressure_solve")
+
+    def timers(self, reset=False):
+        """wall-clock per PerformanceLog label of the reference (logging.py:34-60): {label: (seconds, calls)}"""
+        sec, cnt = np.zeros(4), np.zeros(4, dtype=np.int64)
+        self._ck(self.lib.hdgcpu_get_timers(self.h, _p(sec), cnt.ctypes.data_as(C.POINTER(C.c_long)), C.c_int(1 if reset else 0)))
+        return {lab: (float(sec[k]), int(cnt[k])) for k, lab in enumerate(self.TIMER_LABELS)}
+
     def node_coordinates(self):
         xq, xp = np.empty(self.shape_Q), np.empty((self.n_cells * self.n_p, 2))
         self._ck(self.lib.hdgcpu_node_coordinates(self.h, _p(xq), _p(xp)))

@@ -729,26 +729,45 @@ struct Twin {
 
   // ------------------------------------------------------------------ one step (hdg_imex.py:551-637)
   vec wQ3, wQ4, wP1, wL1, wL2, rhs;
+  // wall-clock per PerformanceLog label (logging.py:34-60; the labels of hdg_imex.py:551,564,569,575,625,631):
+  // 0 timestep, 1 bdm_projection, 2 tentative_velocity_solve, 3 pressure_solve   [seconds, calls]
+  double tm_sec[4] = {0, 0, 0, 0};
+  long tm_cnt[4] = {0, 0, 0, 0};
+  struct Tm {
+    Twin& t; int k; double t0;
+    Tm(Twin& t_, int k_) : t(t_), k(k_), t0(omp_get_wtime()) {}
+    ~Tm() { t.tm_sec[k] += omp_get_wtime() - t0; t.tm_cnt[k]++; }
+  };
   void step() {
     if (!cfg.use_projection) throw std::string("the CPU twin implements the projection method only");
     if (wQ3.empty()) { wQ3 = curQ; wQ4 = curQ; rhs = curQ; wP1 = curP; wL1 = curL; wL2 = curL; }
+    Tm tstep(*this, 0);
     stQ[0] = curQ; stP[0] = curP; stL[0] = curL;
     for (int i = 1; i < s; i++) {
-      bdm(stQ[i - 1], Qstar[i - 1]);
+      { Tm tb(*this, 1); bdm(stQ[i - 1], Qstar[i - 1]); }
       const double gamma = cfg.a_impl[i * s + i] * cfg.dt;
       ensure_hyb(i, gamma);
       for (int r = 0; r < cfg.n_richardson; r++) {
-        std::vector<double> cq, cb;
-        residual_coeffs(i, cq, cb);
-        residual_vector(cq, cb, wQ3);
-        adv(stQ[i], Qstar[i - 1], wQ4, gamma, nullptr);
-        pgrad(&wQ3, 1.0, &wQ4, -1.0, stP[i], stL[i], gamma, rhs);
-        const int it = gmres(Qstar[i - 1], gamma, i, rhs, Qtent[i]);
+        int it;
+        {
+          // the label covers what tentative_velocity_solve() does in the reference: right-hand side and solve
+          Tm tt(*this, 2);
+          std::vector<double> cq, cb;
+          residual_coeffs(i, cq, cb);
+          residual_vector(cq, cb, wQ3);
+          adv(stQ[i], Qstar[i - 1], wQ4, gamma, nullptr);
+          pgrad(&wQ3, 1.0, &wQ4, -1.0, stP[i], stL[i], gamma, rhs);
+          it = gmres(Qstar[i - 1], gamma, i, rhs, Qtent[i]);
+        }
         it_sum[0] += it; it_cnt[0]++;
-        weak_div(Qtent[i], -1.0 / gamma, wP1);
-        condense(nullptr, &wP1, nullptr, wL1);
-        const int itp = trace_cg(wL1, updL);
-        backsub(nullptr, &wP1, updL, updU, updP);
+        int itp;
+        {
+          Tm tp(*this, 3);
+          weak_div(Qtent[i], -1.0 / gamma, wP1);
+          condense(nullptr, &wP1, nullptr, wL1);
+          itp = trace_cg(wL1, updL);
+          backsub(nullptr, &wP1, updL, updU, updP);
+        }
         it_sum[1] += itp; it_cnt[1]++;
         shift(updP, &updL);
         lincomb({{&stQ[i], 1.0}, {&Qtent[i], 1.0}, {&updU, gamma}}, stQ[i]);
@@ -761,12 +780,14 @@ struct Twin {
       std::vector<double> cq, cb;
       final_residual_coeffs(cq, cb);
       residual_vector(cq, cb, wQ3);
+      Tm tp(*this, 3);
       condense(&wQ3, nullptr, nullptr, wL1);
       const int it = trace_cg(wL1, curL);
       backsub(&wQ3, nullptr, curL, curQ, curP);
       it_sum[2] += it; it_cnt[2]++;
     }
     {
+      Tm tp(*this, 3);
       precon_rhs(curQ, bvec(s), bscale[s], wP1, wL2);
       condense(nullptr, &wP1, &wL2, wL1);
       const int it = trace_cg(wL1, recL);
@@ -935,6 +956,16 @@ int hdgcpu_get_iteration_stats(Handle* h, double* sums, long* counts, int reset)
   CPU_END(h)
 }
 // physical coordinates of the velocity / pressure nodes in boundary numbering (what `interpolate` evaluates at)
+// wall-clock seconds and call counts per label (0 timestep, 1 bdm_projection, 2 tentative_velocity_solve, 3 pressure_solve)
+int hdgcpu_get_timers(Handle* h, double* seconds, long* calls, int reset) {
+  CPU_BEGIN(h)
+  for (int k = 0; k < 4; k++) {
+    if (seconds) seconds[k] = E.tm_sec[k];
+    if (calls) calls[k] = E.tm_cnt[k];
+    if (reset) { E.tm_sec[k] = 0.0; E.tm_cnt[k] = 0; }
+  }
+  CPU_END(h)
+}
 int hdgcpu_node_coordinates(Handle* h, double* xq, double* xp) {
   CPU_BEGIN(h)
   for (int which = 0; which < 2; which++) {
