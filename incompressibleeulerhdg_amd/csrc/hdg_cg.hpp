@@ -11,7 +11,8 @@
 //   vertex (i,j) | p-1 interior nodes of H(i,j), V(i,j), D(i,j) | (p-1)(p-2)/2 interior nodes of L(i,j), U(i,j)     p = k+1
 // in ONE contiguous vector [vertices | H | V | D | interiors].  A cell reaches its dofs through a small per-shape table
 // (CgTabs::fwd, built and cross-checked against node coordinates on the host); a dof gathers from its (at most six)
-// cells through the inverse table -- owner computes, no atomics, bitwise reproducible.
+// cells through the inverse table -- owner computes, no atomics, bitwise reproducible.  On the doubly periodic square
+// (driver.py:182-183) the corner indices wrap: nx x ny corners, every one with its three edges and two cells.
 // The mass matrix of the continuous space is never formed: apply = per cell (gather nodal values, local mass
 // Mloc = Vinv^T Vinv) -> per dof (sum over incident cells), solved by Jacobi-preconditioned CG.
 #pragma once
@@ -22,6 +23,7 @@ namespace hdg {
 struct CgTabs {
   int p, nint;                 // polynomial degree k+1, interior nodes per cell
   int nx, ny;
+  int per, vs;                 // doubly periodic square: corner indices wrap; vs = vertex columns (nx + 1, or nx when periodic)
   long baseH, baseV, baseD, baseI, ncg;
   short fwd[2][21][4];         // [shape][local node] -> {type 0 vertex 1 H 2 V 3 D 4 interior, di, dj, t}
   short vtx[6][4];             // vertex gathers from {shape, ci, cj, node}: cell (shape, i+ci, j+cj)
@@ -30,10 +32,14 @@ struct CgTabs {
 };
 
 __device__ __forceinline__ long cg_dof(const CgTabs& C, int type, int I, int J, int t, int s) {
+  if (C.per) {  // corner (nx, j) is corner (0, j), corner (i, ny) is corner (i, 0)
+    if (I >= C.nx) I -= C.nx;
+    if (J >= C.ny) J -= C.ny;
+  }
   switch (type) {
-    case 0: return (long)J * (C.nx + 1) + I;
+    case 0: return (long)J * C.vs + I;
     case 1: return C.baseH + ((long)J * C.nx + I) * (C.p - 1) + t;
-    case 2: return C.baseV + ((long)J * (C.nx + 1) + I) * (C.p - 1) + t;
+    case 2: return C.baseV + ((long)J * C.vs + I) * (C.p - 1) + t;
     case 3: return C.baseD + ((long)J * C.nx + I) * (C.p - 1) + t;
     default: return C.baseI + (((long)J * C.nx + I) * 2 + s) * C.nint + t;
   }
@@ -139,7 +145,8 @@ template <int K>
 __global__ __launch_bounds__(128) void k_cg_gather(Geo g, CgTabs C, const double* __restrict__ y, double* __restrict__ out) {
   HDG_CORNER_PROLOGUE
   auto cellval = [&](const short* f) -> double {
-    const int ci = i + f[1], cj = j + f[2];
+    int ci = i + f[1], cj = j + f[2];
+    if (C.per) { ci = ci < 0 ? ci + g.nx : ci; cj = cj < 0 ? cj + g.ny : cj; }  // the cells on the other side of the seam
     if (ci < 0 || cj < 0 || ci >= g.nx || cj >= g.ny) return 0.0;
     return y[(long)f[3] * g.Nc + cidx(g, f[0], cj, ci)];
   };

@@ -2080,17 +2080,19 @@ struct Engine {
   void cg_setup() {
     if (cg_ready) return;
     if (comm->size > 1) throw std::string("the continuous space (tracer, vorticity) is implemented for a single rank");
-    if (periodic) throw std::string("the continuous space (tracer, vorticity) is not implemented on the periodic mesh");
     const int p = K + 1;
     std::vector<real> xi, eta;
     triangleNodes(p, cfg.equispaced_nodes, xi, eta);
     if ((int)xi.size() != NU) throw std::string("node count mismatch");
     std::memset(&cgt, 0, sizeof(cgt));
     cgt.p = p; cgt.nint = (p - 1) * (p - 2) / 2; cgt.nx = g.nx; cgt.ny = g.ny;
-    const long nvt = (long)(g.nx + 1) * (g.ny + 1);
+    cgt.per = periodic ? 1 : 0;
+    cgt.vs = periodic ? g.nx : g.nx + 1;
+    const long nrows = periodic ? g.ny : g.ny + 1;  // corner rows that carry vertices / horizontal edges
+    const long nvt = (long)cgt.vs * nrows;
     cgt.baseH = nvt;
-    cgt.baseV = cgt.baseH + (long)g.nx * (g.ny + 1) * (p - 1);
-    cgt.baseD = cgt.baseV + (long)(g.nx + 1) * g.ny * (p - 1);
+    cgt.baseV = cgt.baseH + (long)g.nx * nrows * (p - 1);
+    cgt.baseD = cgt.baseV + (long)cgt.vs * g.ny * (p - 1);
     cgt.baseI = cgt.baseD + (long)g.nx * g.ny * (p - 1);
     cgt.ncg = cgt.baseI + 2L * g.nx * g.ny * cgt.nint;
     // forward table from the lattice index (a, b) of each node (order: for b: for a), checked against coordinates below
@@ -2248,13 +2250,14 @@ struct Engine {
     triangleNodes(p, cfg.equispaced_nodes, xi, eta);
     const double h = g.h;
     auto put = [&](long id, double x, double y) { xy[2 * id] = x; xy[2 * id + 1] = y; };
-    for (int j = 0; j <= g.ny; j++)
-      for (int i = 0; i <= g.nx; i++) {
-        put((long)j * (g.nx + 1) + i, i * h, j * h);
+    const int jmax = periodic ? g.ny - 1 : g.ny, imax = periodic ? g.nx - 1 : g.nx;  // periodic: nx x ny corners
+    for (int j = 0; j <= jmax; j++)
+      for (int i = 0; i <= imax; i++) {
+        put((long)j * cgt.vs + i, i * h, j * h);
         for (int t = 0; t < p - 1; t++) {
           const double tt = (double)gl[t + 1];
           if (i < g.nx) put(cgt.baseH + ((long)j * g.nx + i) * (p - 1) + t, (i + tt) * h, j * h);
-          if (j < g.ny) put(cgt.baseV + ((long)j * (g.nx + 1) + i) * (p - 1) + t, i * h, (j + tt) * h);
+          if (j < g.ny) put(cgt.baseV + ((long)j * cgt.vs + i) * (p - 1) + t, i * h, (j + tt) * h);
           if (i < g.nx && j < g.ny) put(cgt.baseD + ((long)j * g.nx + i) * (p - 1) + t, (i + 1 - tt) * h, (j + tt) * h);
         }
         if (i < g.nx && j < g.ny)

@@ -2,10 +2,11 @@
 
     python -m incompressibleeulerhdg_amd.driver --nx 64 --degree 2 --use_projection_method
 
-Out of scope here: the ``kelvinhelmholtz`` / ``shear`` problems (unstructured / periodic
-meshes) and the ``conforming`` / ``dg`` discretisations.  ``--animation`` (evolution.pvd with the CG vorticity,
-callbacks.py:30-85) and ``--tracer_advection`` (driver.py:340-344) are supported.  The final fields are
-written to ``solution.pvd`` (``--output``) like the reference does (driver.py:356-385).
+``--problem taylorgreen`` (unit square) and ``--problem shear`` (doubly periodic square, driver.py:182-183) are built;
+``kelvinhelmholtz`` needs the unstructured disk mesh and raises, as do the ``conforming`` / ``dg`` discretisations
+(SURVEY.md section 2.1).  ``--animation`` (evolution.pvd with the CG vorticity, callbacks.py:30-85) and
+``--tracer_advection`` (driver.py:340-344) work on both meshes.  The final fields are written to ``solution.pvd``
+(``--output``) like the reference does (driver.py:356-385).
 """
 import argparse
 import sys

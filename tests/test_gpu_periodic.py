@@ -91,6 +91,59 @@ def test_periodic_imex_steps(hip_lib, k, nx, tableau):
     assert _rel(oQ, d.interpolate_velocity(Q0)) > 1e-3
 
 
+@pytest.mark.parametrize("k,nx", [(1, 4), (2, 4), (3, 4), (2, 6)])
+def test_periodic_continuous_space_tracer_operator_vorticity(hip_lib, k, nx):
+    """CG_{k+1} on the periodic square (nx x ny corners, indices wrap): projection (common.py:119-122), tracer transport
+    form (common.py:110-129) and vorticity (callbacks.py:43-69) against oracle/tracer_oracle.py on the periodic mesh."""
+    from oracle.tracer_oracle import TracerOracle
+
+    d, e = _setup(k, nx)
+    tr = TracerOracle(d)
+    assert e.cg_size() == tr.ncg == ((k + 1) * nx) ** 2
+    key = lambda X: {tuple(np.round(x * nx / L * 1e6).astype(np.int64)) for x in X}
+    assert key(e.cg_coordinates()) == key(tr.cg_coords) and len(key(e.cg_coordinates())) == tr.ncg
+    rng = np.random.default_rng(5)
+    u = rng.standard_normal(e.shape_Q)
+    P = e.cg_project_nodal(u)
+    assert _rel(P, tr.cg_project(u)) < 1e-10 and _rel(e.cg_project_nodal(P), P) < 1e-10
+    cont = d.interpolate_velocity(lambda x, y: (np.sin(x) * np.cos(2 * y), np.cos(x + y)))  # smooth and periodic
+    assert _rel(e.cg_project_nodal(cont), tr.cg_project(cont)) < 1e-10
+    q = rng.standard_normal(e.shape_p)
+    assert _rel(e.apply_tracer_advection(q, u, project=True), tr.tracer_tendency(q, u)) < 1e-10
+    uc = tr.cg_project(u)
+    assert _rel(e.apply_tracer_advection(q, uc, project=False), tr._lu_mp.solve(tr.tracer_form(q, uc))) < 1e-10
+    Q = rng.standard_normal(e.shape_Q)
+    w, xy = tr.vorticity(Q)
+    wd = e.vorticity(Q)
+    order = lambda X: np.lexsort((np.round(X[:, 1] * nx / L * 1e6), np.round(X[:, 0] * nx / L * 1e6)))
+    assert _rel(wd[order(e.cg_coordinates())], w[order(xy)]) < 1e-10
+    assert _rel(e.cg_to_broken(wd), tr.R @ w) < 1e-10
+
+
+@pytest.mark.parametrize("k,nx,tableau", [(1, 6, "imex_ssp2_332"), (2, 4, "imex_ars3_443")])
+def test_periodic_imex_steps_with_tracer(hip_lib, k, nx, tableau):
+    """Shear flow + passive tracer on the periodic square (driver.py:182-183,340-344), fused and per-call paths."""
+    from incompressibleeulerhdg_amd import timesteppers as tsm
+    from incompressibleeulerhdg_amd.mesh import PeriodicSquareMesh
+    from oracle import hdg_oracle as orc
+    from oracle.tracer_oracle import TracerOracle, imex_with_tracer
+
+    cls = {"imex_ssp2_332": tsm.IncompressibleEulerHDGIMEXSSP2_332, "imex_ars3_443": tsm.IncompressibleEulerHDGIMEXARS3_443}[tableau]
+    d = orc.HDGDiscretisation(nx, k, periodic=True, L=L)
+    dt, nsteps = 0.25 * d.mesh.h, 2
+    Q0, p0 = _shear()
+    q0 = lambda x, y: np.sin(x) * np.sin(y)
+    f = lambda t: (lambda x, y: (0.1 * np.cos(y) * np.cos(t), 0.2 * np.sin(x + y)))
+    o = orc.OracleHDGIMEX(d, dt, tableau)
+    oQ, op, oq = imex_with_tracer(o, TracerOracle(d), d.interpolate_velocity(Q0), d.interpolate_pressure(p0), d.interpolate_pressure(q0),
+                                  lambda t: d.interpolate_velocity(f(t)), nsteps * dt)
+    for fused in (False, True):
+        ts = cls(PeriodicSquareMesh(nx, nx, L=L), k, dt)
+        Q, p = ts.solve(Q0, p0, q0, f, nsteps * dt, fused=fused)
+        assert _rel(Q.dat.data, oQ) < TOL and _rel(p.dat.data, op) < TOL and _rel(ts.q_tracer.dat.data, oq) < TOL, fused
+    assert _rel(oq, d.interpolate_pressure(q0)) > 1e-3  # the tracer moved
+
+
 @pytest.mark.parametrize("proj", [True, False])
 def test_periodic_implicit_stepper(hip_lib, proj):
     from incompressibleeulerhdg_amd.mesh import PeriodicSquareMesh
@@ -114,9 +167,10 @@ def test_driver_shear_flow(hip_lib, tmp_path, capsys, monkeypatch):
 
     monkeypatch.chdir(tmp_path)
     rc = driver.main(["--problem", "shear", "--nx", "32", "--degree", "2", "--dt", "0.02", "--tfinal", "0.06", "--use_projection_method",
-                      "--fused", "--output", "shear.pvd"])
+                      "--fused", "--output", "shear.pvd", "--tracer_advection", "--animation"])
     out = capsys.readouterr().out
     assert rc == 0 and "model problem = shear" in out and (tmp_path / "shear.pvd").exists()
+    assert "advect tracer = True" in out and (tmp_path / "evolution.pvd").exists()  # vorticity + tracer frames on the periodic mesh
     its = float(out.split("pressure its                :")[1].split()[0])
     assert 0 < its < 25, out
 

@@ -4,7 +4,7 @@
 # PerformanceLog summary the driver prints (label `timestep`), bench lines for the IMEX cases.
 O=${1:-gpurun_out/other}
 mkdir -p $O
-D="python -m incompressibleeulerhdg_amd.driver --output ''"
+D="python -m incompressibleeulerhdg_amd.driver --output="
 # C1: HDG implicit, k=1, 16x16, dt 0.05, 20 steps, projection on / off (monolithic)
 $D --timestepper implicit --degree 1 --nx 16 --dt 0.05 --tfinal 1.0 --use_projection_method --fused > $O/c1_proj.log 2>&1
 $D --timestepper implicit --degree 1 --nx 16 --dt 0.05 --tfinal 1.0 --fused > $O/c1_mono.log 2>&1
