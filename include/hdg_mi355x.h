@@ -166,8 +166,14 @@ int hdg_get_iteration_stats(hdg_handle* h, double* sums, long* counts, int reset
  * step), so hdg_step / hdg_run_separable report the same per-solve breakdown as the per-solve calls.  For each label
  * total_ms[i], sumsq_ms[i] (sum of squares, for the standard deviation log_summary prints) and ncalls[i] since the
  * last reset. */
-#define HDG_N_TIMERS 5
+#define HDG_N_TIMERS 7
 int hdg_get_timers(hdg_handle* h, double* total_ms, double* sumsq_ms, long* ncalls, int reset);
+/* Labels 5 and 6 (no reference counterpart; the measurement SURVEY.md section 8(d) asks for): every launch of the two
+ * kernels of a tentative-velocity iteration -- 5: advection operator (k <= 2: residual form b - (I - gamma F) x of the
+ * Chebyshev iteration; k >= 3: the plain operator GMRES applies), 6: hybrid edge-lift preconditioner (with the fused
+ * Chebyshev step / plain) -- bracketed by its own event pair IN PLACE, i.e. with the operands and cache state of the
+ * solve.  Recorded only while switched on (two event records per launch). */
+int hdg_set_kernel_timing(hdg_handle* h, int on);
 
 /* ---- passive tracer.  Explicit DG transport of a scalar in DG_k by the L2 projection of
  * the stage velocity onto [CG_{k+1}]^2 (common.py:110-129): q_i = q_0 + dt sum_{j<i} a_expl[i,j] M^-1 T(q_j, P(Q_i))

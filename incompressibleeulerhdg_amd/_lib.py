@@ -120,6 +120,7 @@ SIGNATURES = {
     "hdg_implicit_step": [_h, _ip, _ip],
     "hdg_get_iteration_stats": [_h, _dp, _lp, C.c_int],
     "hdg_get_timers": [_h, _dp, _dp, _lp, C.c_int],
+    "hdg_set_kernel_timing": [_h, C.c_int],
     "hdg_set_tracer": [_h, _dp],
     "hdg_get_tracer": [_h, _dp],
     "hdg_tracer_begin_step": [_h],
@@ -405,13 +406,20 @@ class Engine:
         return out
 
     TIMER_LABELS = ("timestep", "bdm_projection", "tentative_velocity_solve", "pressure_solve", "unsplit_solve")
+    KERNEL_TIMER_LABELS = ("kernel_advection", "kernel_lift")  # hdg_set_kernel_timing; no reference counterpart
 
-    def timers(self, reset=False):
-        """Device-side section timers (labels of the reference's PerformanceLog): {label: (ncall, total_s, sumsq_s2)}."""
-        tot, sq = np.zeros(5), np.zeros(5)
-        cnt = np.zeros(5, dtype=np.int64)
+    def timers(self, reset=False, kernels=False):
+        """Device-side section timers (labels of the reference's PerformanceLog): {label: (ncall, total_s, sumsq_s2)};
+        kernels=True adds the per-launch brackets of the two kernels of a tentative-velocity iteration."""
+        n = 7
+        tot, sq = np.zeros(n), np.zeros(n)
+        cnt = np.zeros(n, dtype=np.int64)
         self._ck(self.lib.hdg_get_timers(self.h, _ptr(tot), _ptr(sq), cnt.ctypes.data_as(_lp), 1 if reset else 0))
-        return {lab: (int(c), t * 1e-3, q * 1e-6) for lab, c, t, q in zip(self.TIMER_LABELS, cnt, tot, sq)}
+        labels = self.TIMER_LABELS + (self.KERNEL_TIMER_LABELS if kernels else ())
+        return {lab: (int(c), t * 1e-3, q * 1e-6) for lab, c, t, q in zip(labels, cnt, tot, sq)}
+
+    def set_kernel_timing(self, on):
+        self._ck(self.lib.hdg_set_kernel_timing(self.h, 1 if on else 0))
 
     # --- helpers
     def node_coordinates(self):

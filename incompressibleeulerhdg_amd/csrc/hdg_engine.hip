@@ -126,9 +126,12 @@ struct Engine {
   // ------------------------------------------------------------------ section timers (hdg_get_timers)
   // Sections are bracketed by events on the stream; elapsed times are harvested once the stream has drained
   // (the end of every API call), so a fused step needs no synchronisation to report its per-solve breakdown.
-  enum { T_STEP = 0, T_BDM = 1, T_TENT = 2, T_PRESS = 3, T_UNSPLIT = 4 };
-  double tm_total[HDG_N_TIMERS] = {0, 0, 0, 0, 0}, tm_sumsq[HDG_N_TIMERS] = {0, 0, 0, 0, 0};
-  long tm_calls[HDG_N_TIMERS] = {0, 0, 0, 0, 0};
+  // T_KADV / T_KLIFT (hdg_set_kernel_timing): every launch of the two kernels of a tentative-velocity iteration -- the
+  // advection operator in residual form and the hybrid lift with its Chebyshev / GMRES epilogue -- bracketed on its own,
+  // in place (same operands, same cache state as in the solve): what bench.py's roofline block divides by.
+  enum { T_STEP = 0, T_BDM = 1, T_TENT = 2, T_PRESS = 3, T_UNSPLIT = 4, T_KADV = 5, T_KLIFT = 6 };
+  double tm_total[HDG_N_TIMERS] = {0, 0, 0, 0, 0, 0, 0}, tm_sumsq[HDG_N_TIMERS] = {0, 0, 0, 0, 0, 0, 0};
+  long tm_calls[HDG_N_TIMERS] = {0, 0, 0, 0, 0, 0, 0};
   struct Section { int label; hipEvent_t e0, e1; };
   std::vector<Section> tm_open;       // recorded, not yet harvested
   std::vector<hipEvent_t> tm_pool;    // idle events
@@ -151,6 +154,16 @@ struct Engine {
       (void)hipEventRecord(sec.e1, E.stream);
       E.tm_open.push_back(sec);
     }
+  };
+  bool kernel_timing = false;
+  struct KTimed {  // Timed, but only while kernel timing is switched on
+    Engine& E; bool on; Section sec;
+    KTimed(Engine& e, int label, bool cond) : E(e), on(e.kernel_timing && cond) {
+      if (!on) return;
+      sec.label = label; sec.e0 = E.tm_event(); sec.e1 = E.tm_event();
+      (void)hipEventRecord(sec.e0, E.stream);
+    }
+    ~KTimed() { if (on) { (void)hipEventRecord(sec.e1, E.stream); E.tm_open.push_back(sec); } }
   };
   void harvest_timers() {  // the stream must have been synchronised
     for (const Section& sc : tm_open) {
@@ -624,6 +637,7 @@ struct Engine {
     const int ext = lift_ext(in, nullptr, chd_, chx_, c1);
     const Geo gx = g_ext(ext);
     fl.set(out, ext); fl.set(chd_, ext);
+    KTimed kt_(*this, T_KLIFT, fl.active() && ((cfg.tent_solver == 1) == (chd_ != nullptr)));
     if (use_mfma_lift() && out && !chd_ && !ss) {
       // GMRES path at k >= 3: no Chebyshev epilogue -> matrix-core kernel with the packed G tables of this stage
       for (size_t q = 0; q < hybg0.size(); q++)
@@ -642,6 +656,7 @@ struct Engine {
     const Geo g = g_ext(ext);  // this launch's copy (row extension); shadows the member on purpose
     fl.set(out, ext);
     const dim3 cgrid = cell_grid_of(g);
+    KTimed kt_(*this, T_KADV, fl.active() && ((cfg.tent_solver == 1) == (bsub != nullptr)));
     const double up = cfg.flux_upwind ? 1.0 : 0.0;
     // k >= 3: the whole operator on the matrix cores (k_adv_mfma); HDG_NO_MFMA_ADV falls back to the per-thread kernels
     static const bool no_mfma_adv = std::getenv("HDG_NO_MFMA_ADV") != nullptr;
@@ -2675,6 +2690,11 @@ int hdg_get_timers(hdg_handle* h, double* total_ms, double* sumsq_ms, long* ncal
     if (ncalls) ncalls[i] = E.tm_calls[i];
     if (reset) { E.tm_total[i] = 0; E.tm_sumsq[i] = 0; E.tm_calls[i] = 0; }
   }
+  HDG_API_END(h)
+}
+int hdg_set_kernel_timing(hdg_handle* h, int on) {
+  HDG_API_BEGIN(h)
+  E.kernel_timing = on != 0;
   HDG_API_END(h)
 }
 // ---- passive tracer and continuous-space diagnostics

@@ -215,6 +215,25 @@ def test_section_timers_across_the_abi(hip_lib):
     assert 0 < parts <= t["timestep"][1] * 1.001
     assert parts > 0.5 * t["timestep"][1]  # the three sections are the bulk of a step
     assert e.timers(reset=True)["timestep"][0] == nsteps and e.timers()["timestep"][0] == 0
+    # kernel-level brackets (hdg_set_kernel_timing): off by default; on, every launch of the two kernels of a
+    # tentative-velocity iteration is timed in place: as many as iterations (+ the first residual of each solve), and their
+    # sum stays inside the tentative-velocity section
+    assert e.timers(kernels=True)["kernel_advection"][0] == 0
+    e.set_kernel_timing(True)
+    e.iteration_stats(reset=True)
+    for sl in range(4):
+        e.set_forcing_scale(sl, -0.5)
+    e.step()
+    tk = e.timers(reset=True, kernels=True)
+    sums, cnt = e.iteration_stats()
+    e.set_kernel_timing(False)
+    n_adv, n_lift = tk["kernel_advection"][0], tk["kernel_lift"][0]
+    assert n_adv > 0 and n_lift > 0 and abs(n_adv - n_lift) <= 2 * cnt[0]
+    assert 0.7 * sums[0] <= n_lift <= sums[0] + 2 * cnt[0], (n_lift, sums, cnt)  # one lift per Chebyshev iteration
+    assert 0 < tk["kernel_advection"][1] + tk["kernel_lift"][1] <= tk["tentative_velocity_solve"][1] * 1.001
+    e.step()
+    assert e.timers(kernels=True)["kernel_advection"][0] == 0  # switched off again
+    e.timers(reset=True)
     # the class surface feeds them to the reference's summary table when the steps are fused
     ts.solve(*mp.initial_condition(), None, mp.f_rhs(), 2 * dt, fused=True)
     buf = io.StringIO()
