@@ -2268,14 +2268,19 @@ __device__ __forceinline__ void p1_stencil_lds(const double* x, int n, int i, in
 }
 __device__ __forceinline__ void p1_sweeps_lds(double* x, const double* b, int n, int sweeps, bool reverse) {
   const int npts = (n + 1) * (n + 1);
+  // n even (every level of the tail): the row length is odd, so the points of colour c are exactly the odd / even linear
+  // indices: every thread of a trip has work (n = 32: one trip of 545 points instead of two over 1089).  The diagonal is
+  // 4, 2 or 1, so the multiplication by its inverse is exact (bitwise equal to the division of k_p1_rbgs).
+  const int step = (n & 1) ? 1 : 2;
   for (int sw = 0; sw < 2 * sweeps; sw++) {
     const int colour = ((sw & 1) == 0) ? (reverse ? 1 : 0) : (reverse ? 0 : 1);
-    for (int p = threadIdx.x; p < npts; p += blockDim.x) {
+    for (int p = step * threadIdx.x + (step == 2 ? colour : 0); p < npts; p += step * blockDim.x) {
       const int j = p / (n + 1), i = p - j * (n + 1);
-      if (((i + j) & 1) == colour) {
+      if (step == 2 || ((i + j) & 1) == colour) {
         double diag, off;
         p1_stencil_lds(x, n, i, j, diag, off);
-        x[p] = (b[p] + off) / diag;
+        const double inv = diag == 4.0 ? 0.25 : (diag == 2.0 ? 0.5 : 1.0 / diag);
+        x[p] = (b[p] + off) * inv;
       }
     }
     __syncthreads();
