@@ -30,5 +30,8 @@ cd $R
 python3 bench.py > $O/bench_c3.json 2> $O/bench_c3.err
 python3 bench.py --degree 3 --nx 512 --no-cpu-baseline > $O/bench_k3.json 2> $O/bench_k3.err
 python3 bench.py --degree 4 --nx 512 --no-cpu-baseline > $O/bench_k4.json 2> $O/bench_k4.err
-find $O -name "*.csv" | head -50
-tail -c 400 $O/bench_c3.json
+# summarise here: the raw counter / trace CSVs are larger than what gpurun copies back
+python3 tools/summarise_profiles.py $TAG $R/gpurun_out/summary_$TAG > $R/gpurun_out/summary_$TAG.log 2>&1
+tail -25 $R/gpurun_out/summary_$TAG.log
+rm -rf $O
+ls $R/gpurun_out/summary_$TAG

@@ -1,12 +1,15 @@
 """Turn the raw rocprofv3 output of tools/collect_profiles.sh (gpurun_out/prof_TAG/) into the tracked summaries
-profiles/TAG_* and profiles/pmc_traffic.json.  usage: python tools/summarise_profiles.py TAG"""
+profiles/TAG_* and profiles/pmc_traffic.json.  usage: python tools/summarise_profiles.py TAG [OUTDIR]
+(collect_profiles.sh runs it on the GPU box with OUTDIR = gpurun_out/summary_TAG and deletes the raw traces, which exceed
+what gpurun copies back; the summaries are then copied into profiles/)."""
 import collections, csv, glob, json, os, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 tag = sys.argv[1]
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
-dst = os.path.join(ROOT, "profiles")
+dst = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles")
+os.makedirs(dst, exist_ok=True)
 
 
 def find(sub, pat):
@@ -63,7 +66,16 @@ for what, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
         k = [n for n in t if n.startswith("k_axpby<true>")]  # the velocity-sized launches (streaming cache policy)
         if k:
             cal[ctr] = t[k[0]][ctr]
-NQ_C3 = 41943040 + 2 * 2 * 10 * 2 * 1024  # velocity vector incl. the two ghost rows
+def rows_per_plane(nx, ny, gh=4):  # Engine::construct: ghost rows + the stride padding rule
+    R = ny + 2 * gh
+    for pad in range(64):
+        t = ((2 * nx * (R + pad) * 16) % 524288) / 32768.0
+        if 2.5 <= t <= 7.5 or 10.5 <= t <= 15.5:
+            return R + pad
+    return R
+
+
+NQ_C3 = 2 * 10 * 2 * 1024 * rows_per_plane(1024, 1024)  # velocity vector incl. ghost and padding rows (k_axpby runs over all)
 triad_read_KiB, triad_write_KiB = 2 * 8 * NQ_C3 / 1024, 8 * NQ_C3 / 1024
 f_fetch = triad_read_KiB / cal["FETCH_SIZE"] if "FETCH_SIZE" in cal else 2.0
 f_write = triad_write_KiB / cal["WRITE_SIZE"] if "WRITE_SIZE" in cal else 1.0
