@@ -1,6 +1,7 @@
 """Worker of tests/test_gpu_multirank.py: one rank of a strip-partitioned HDG-IMEX run.
 
-usage: mp_strip_worker.py RANK NRANKS TOKEN K NX NSTEPS OUTFILE [unsplit] [badtimer]
+usage: mp_strip_worker.py RANK NRANKS TOKEN K NX NSTEPS OUTFILE [unsplit] [badtimer] [opt:NAME=INT ...]
+(opt: engine options of the timestepper classes, e.g. opt:tent_precond=1 opt:tent_solver=0 opt:trace_precond=0)
 """
 import os
 import sys
@@ -15,6 +16,7 @@ def main():
                                                int(sys.argv[5]), int(sys.argv[6]), sys.argv[7])
     unsplit = "unsplit" in sys.argv[8:]
     badtimer = "badtimer" in sys.argv[8:]
+    opts = {a[4:].split("=")[0]: int(a.split("=")[1]) for a in sys.argv[8:] if a.startswith("opt:")}
     from incompressibleeulerhdg_amd import _lib
     from incompressibleeulerhdg_amd.mesh import UnitSquareMesh
     from incompressibleeulerhdg_amd.model_problems import TaylorGreen
@@ -22,7 +24,7 @@ def main():
 
     dt = 0.25 / nx
     ts = IncompressibleEulerHDGIMEXSSP2_332(UnitSquareMesh(nx, nx), k, dt, use_projection_method=not unsplit,
-                                            n_richardson=2, rank=rank, nranks=nranks, comm_backend="shm", comm_token=token)
+                                            n_richardson=2, rank=rank, nranks=nranks, comm_backend="shm", comm_token=token, **opts)
     mp = TaylorGreen(ts._V_Q, ts._V_p)
     if badtimer:
         # a failed micro-benchmark call (unknown kernel id) must leave the halo exchanges switched ON: the step

@@ -86,6 +86,34 @@ def test_strip_partition_matches_single_rank(hip_lib, tmp_path, nranks, k, nx):
     assert abs(parts[0]["its"][0] - its1[0]) <= max(4.0, 0.25 * its1[0])
 
 
+@pytest.mark.parametrize("nranks,k,nx,opts", [
+    (2, 2, 16, {"tent_precond": 1}),                    # additive two-level preconditioner: Pi^T, then lift + block-Jacobi
+    (2, 1, 16, {"tent_precond": 0}),                    # block-Jacobi only (no stencil in the preconditioner)
+    (3, 2, 12, {"tent_solver": 0}),                     # GMRES(8) instead of the Chebyshev iteration
+    (2, 2, 16, {"tent_solver": 0, "tent_precond": 1}),
+    (2, 2, 16, {"trace_precond": 0}),                   # edge block-Jacobi instead of the multigrid V-cycle
+    (4, 1, 16, {"gmres_restart": 4, "tent_solver": 0}),
+])
+def test_strip_partition_with_the_other_solver_paths(hip_lib, tmp_path, nranks, k, nx, opts):
+    """The ghost-row bookkeeping (Engine::Flow) serves every solver configuration: each alternative preconditioner /
+    Krylov method on several ranks reproduces the single-rank run with the same options."""
+    from incompressibleeulerhdg_amd import _lib
+    from incompressibleeulerhdg_amd.mesh import UnitSquareMesh
+    from incompressibleeulerhdg_amd.model_problems import TaylorGreen
+    from incompressibleeulerhdg_amd.timesteppers import IncompressibleEulerHDGIMEXSSP2_332
+
+    nsteps = 2
+    parts = _run_ranks(nranks, k, nx, nsteps, tmp_path, extra=tuple(f"opt:{a}={b}" for a, b in opts.items()))
+    Q, p, lam = _assemble(parts, k, nx)
+    dt = 0.25 / nx
+    ts = IncompressibleEulerHDGIMEXSSP2_332(UnitSquareMesh(nx, nx), k, dt, use_projection_method=True, n_richardson=2, **opts)
+    mp = TaylorGreen(ts._V_Q, ts._V_p)
+    Q1, p1 = ts.solve(*mp.initial_condition(), None, mp.f_rhs(), nsteps * dt, fused=True)
+    lam1 = ts._engine.get_field(_lib.HDG_STATE_CURRENT, Q=False, p=False)[2]
+    rel = lambda a, b: np.max(np.abs(a - b)) / np.max(np.abs(b))
+    assert rel(Q, Q1.dat.data) < 2e-8 and rel(p, p1.dat.data) < 2e-8 and rel(lam, lam1) < 2e-8
+
+
 def test_strip_partition_unsplit(hip_lib, tmp_path):
     from incompressibleeulerhdg_amd.mesh import UnitSquareMesh
     from incompressibleeulerhdg_amd.model_problems import TaylorGreen
