@@ -593,11 +593,14 @@ struct Engine {
   std::vector<double*> liftm_hyb0, liftm_hyb1;         // per stage: hybrid preconditioner
   bool use_mfma_lift() const {
     static const bool off = std::getenv("HDG_NO_MFMA_LIFT") != nullptr;
-    return !off && cfg.degree >= 3 && !periodic;  // the matrix-core kernels do not wrap column indices
+    return !off && cfg.degree >= mfma_min_degree() && !periodic;  // the matrix-core kernels do not wrap column indices
   }
+  // HDG_MFMA_K2 (experiment): the matrix-core kernels at k = 2 as well (north_star: "MFMA at k >= 2")
+  static int mfma_min_degree() { static const int d = std::getenv("HDG_MFMA_K2") ? 2 : 3; return d; }
   void lift_mfma(const Geo& gx, const double* t0, const double* t1, const double* in, double* out) {
     const dim3 grid(8 * gx.rows_xcd * 2);
     switch (cfg.degree) {
+      case 2: k_edge_lift_mfma<2><<<grid, 64 * HDG_LIFT_MFMA_WAVES, 0, stream>>>(gx, t0, t1, in, out); break;
       case 3: k_edge_lift_mfma<3><<<grid, 64 * HDG_LIFT_MFMA_WAVES, 0, stream>>>(gx, t0, t1, in, out); break;
       case 4: k_edge_lift_mfma<4><<<grid, 64 * HDG_LIFT_MFMA_WAVES, 0, stream>>>(gx, t0, t1, in, out); break;
       default: throw std::string("MFMA lift: degree out of range");
@@ -660,14 +663,15 @@ struct Engine {
     const double up = cfg.flux_upwind ? 1.0 : 0.0;
     // k >= 3: the whole operator on the matrix cores (k_adv_mfma); HDG_NO_MFMA_ADV falls back to the per-thread kernels
     static const bool no_mfma_adv = std::getenv("HDG_NO_MFMA_ADV") != nullptr;
-    if (!no_mfma_adv && cfg.degree >= 3 && !periodic) {
+    if (!no_mfma_adv && cfg.degree >= mfma_min_degree() && !periodic) {
       if (!advm[0]) {
-        if (dt.nqc != (cfg.degree == 3 ? 36 : 64)) throw std::string("cell quadrature size does not match the matrix-core advection kernel");
+        if (dt.nqc != (cfg.degree == 2 ? 16 : (cfg.degree == 3 ? 36 : 64))) throw std::string("cell quadrature size does not match the matrix-core advection kernel");
         for (int sh = 0; sh < 2; sh++) advm[sh] = upload(pack_adv_mfma(sh));
       }
       const dim3 gridc(8 * g.rows_xcd * 2);
       if (dt.nqe != (3 * cfg.degree + 5) / 2) throw std::string("edge quadrature size does not match the matrix-core advection kernel");
-      if (cfg.degree == 3) k_adv_mfma<3><<<gridc, 512, 0, stream>>>(g, dt, advm[0], advm[1], x, qstar, out, gamma, up, bsub);
+      if (cfg.degree == 2) k_adv_mfma<2><<<gridc, 512, 0, stream>>>(g, dt, advm[0], advm[1], x, qstar, out, gamma, up, bsub);
+      else if (cfg.degree == 3) k_adv_mfma<3><<<gridc, 512, 0, stream>>>(g, dt, advm[0], advm[1], x, qstar, out, gamma, up, bsub);
       else k_adv_mfma<4><<<gridc, 512, 0, stream>>>(g, dt, advm[0], advm[1], x, qstar, out, gamma, up, bsub);
       return;
     }

@@ -762,7 +762,7 @@ __global__ __launch_bounds__(128) void k_adv_apply2(Geo g, DevTables T, const do
 template <int K>
 struct AdvMfma {
   static constexpr int NU = Dim<K>::NU;
-  static constexpr int NQ = (K == 3) ? 36 : 64;   // cell quadrature points (collapsed Gauss-Jacobi, Tables::nqc)
+  static constexpr int NQ = (K == 2) ? 16 : ((K == 3) ? 36 : 64);  // cell quadrature points (Tables::nqc; k = 2: experiment only)
   static constexpr int MTQ = (NQ + 15) / 16, KSU = (NU + 3) / 4, MTU = (NU + 15) / 16;
   static constexpr int NT1 = MTQ * KSU;            // tiles per stage-1 table
   static constexpr int NTILES = 3 * NT1 + MTU * 4 * MTQ;

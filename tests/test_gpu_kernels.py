@@ -212,3 +212,39 @@ def test_advection_matrix_core_kernel_tiles(hip_lib, k, nx, flux):
     # the operator part alone (the identity would hide a small relative error in F): (x - y) / gamma = M^-1 F x
     Fx = (x.ravel() - ref) / gamma
     assert _relerr((x.ravel() - got.ravel()) / gamma, Fx) < 1e-9
+
+
+def test_matrix_core_kernels_at_k2_behind_the_switch(hip_lib):
+    """HDG_MFMA_K2 (the north_star's "MFMA at k >= 2", measured and rejected -- 1.8-2x slower than
+    the per-thread advection kernel at C3) routes k = 2 through k_adv_mfma<2> / k_edge_lift_mfma<2>.  The switch is read
+    once per process, so the check runs in a child: BDM projection and advection operator (both fluxes) against the
+    oracle on a mesh with a full and a partial 16-cell tile per row."""
+    import os
+    import subprocess
+    import sys
+
+    code = (
+        "import sys, numpy as np, scipy.sparse.linalg as spla\n"
+        "sys.path.insert(0, %r)\n"
+        "from incompressibleeulerhdg_amd._lib import Engine\n"
+        "from oracle.hdg_oracle import HDGDiscretisation, TABLEAUX\n"
+        "k, nx = 2, 20\n"
+        "d = HDGDiscretisation(nx, k)\n"
+        "tb = TABLEAUX['imex_ssp2_332']\n"
+        "rel = lambda a, b: np.max(np.abs(a - b)) / np.max(np.abs(b))\n"
+        "for flux in ('upwind', 'centered'):\n"
+        "    e = Engine(nx=nx, degree=k, dt=0.25 / nx, flux=flux, nstages=3, a_expl=tb['a_expl'], a_impl=tb['a_impl'],\n"
+        "               b_expl=tb['b_expl'], b_impl=tb['b_impl'], c_expl=tb['c_expl'])\n"
+        "    rng = np.random.default_rng(13)\n"
+        "    Q = rng.standard_normal(e.shape_Q)\n"
+        "    assert rel(e.project_bdm_nodal(Q), d.project_bdm(Q)) < 1e-11\n"
+        "    Qstar, x, gamma = d.project_bdm(Q), rng.standard_normal(e.shape_Q), 0.3 / nx\n"
+        "    F = d.assemble_f_impl(Qstar, flux)\n"
+        "    ref = x.ravel() - gamma * spla.spsolve(d.MQ.tocsc(), F @ x.ravel())\n"
+        "    got = e.apply_advection(Qstar, x, gamma)\n"
+        "    assert rel(got.ravel(), ref) < 5e-11\n"
+        "    assert rel((x.ravel() - got.ravel()) / gamma, (x.ravel() - ref) / gamma) < 1e-9\n"
+        "print('ok')\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, HDG_MFMA_K2="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
