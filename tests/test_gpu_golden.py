@@ -54,6 +54,44 @@ def test_implicit_golden(hip_lib, path):
     assert _relerr(Q.dat.data, g["Q"]) < 2e-8 and _relerr(p.dat.data, g["p"]) < 2e-8
 
 
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "tracer_*.npz")) + glob.glob(os.path.join(GOLD, "periodic_*.npz"))))
+def test_tracer_and_periodic_golden(hip_lib, path):
+    """Passive tracer on the unit square (common.py:110-129, hdg_imex.py:415-448) and shear layer + forcing + tracer +
+    vorticity on the doubly periodic square (driver.py:182-183, callbacks.py:43-69) against the committed vectors."""
+    import sys
+
+    sys.path.insert(0, GOLD)
+    from make_golden import periodic_case
+
+    from incompressibleeulerhdg_amd import _lib, timesteppers as ts
+    from incompressibleeulerhdg_amd.mesh import PeriodicSquareMesh, UnitSquareMesh
+    from incompressibleeulerhdg_amd.model_problems import TaylorGreen
+
+    g = np.load(path)
+    kind, rest = os.path.basename(path)[:-len(".npz")].split("_", 1)
+    tab, rest = rest.rsplit("_k", 1)
+    k, nx, n = [int(x.lstrip("nx")) for x in rest.split("_")]
+    cls = {"imex_ars3_443": ts.IncompressibleEulerHDGIMEXARS3_443, "imex_ssp2_332": ts.IncompressibleEulerHDGIMEXSSP2_332}[tab]
+    dt = float(g["dt"])
+    for fused in (True, False):
+        if kind == "tracer":
+            t = cls(UnitSquareMesh(nx, nx), k, dt)
+            mp = TaylorGreen(t._V_Q, t._V_p)
+            q0 = lambda x, y: np.sin(2 * np.pi * x) * np.sin(2 * np.pi * y)
+            Q, p = t.solve(*mp.initial_condition(), q0, mp.f_rhs(), n * dt, fused=fused)
+        else:
+            t = cls(PeriodicSquareMesh(nx, nx, L=2 * np.pi), k, dt)
+            Q0, p0, q0, f = periodic_case()
+            Q, p = t.solve(Q0, p0, q0, f, n * dt, fused=fused)
+            lam = t._engine.get_field(_lib.HDG_STATE_CURRENT, Q=False, p=False)[2]
+            assert _relerr(lam, g["lam"]) < 2e-8
+            w, xy = t._engine.vorticity(), t._engine.cg_coordinates()
+            order = np.lexsort((np.round(xy[:, 1] * 1e6), np.round(xy[:, 0] * 1e6)))
+            assert _relerr(w[order], g["vorticity_sorted"]) < 5e-8
+        assert _relerr(Q.dat.data, g["Q"]) < 2e-8 and _relerr(p.dat.data, g["p"]) < 2e-8, fused
+        assert _relerr(t.q_tracer.dat.data, g["q"]) < 2e-8, fused
+
+
 def test_operator_golden(hip_lib):
     from incompressibleeulerhdg_amd._lib import Engine
 
