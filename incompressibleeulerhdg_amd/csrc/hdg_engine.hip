@@ -1253,7 +1253,9 @@ struct Engine {
     // bim = 0.5 a is within a few iterations of the best value for k = 1, 2 (measured scan), while
     // bim = 0 loses 10+ iterations.
     static const double ell = std::getenv("HDG_CHEB_ELL") ? std::atof(std::getenv("HDG_CHEB_ELL")) : -1.0;
-    const double frac = ell >= 0 ? ell : (cfg.tent_precond == 2 ? 0.5 : 0.0);
+    // k = 2: a THIN ellipse (0.3) for the bulk, then the hand-over to GMRES below; k = 1 (operator so cheap that a GMRES
+    // iteration costs 3-4 Chebyshev iterations): the wider ellipse that converges on its own (scans: DESIGN.md section 9)
+    const double frac = ell >= 0 ? ell : (cfg.tent_precond == 2 ? (cfg.degree >= 2 ? 0.3 : 0.5) : 0.0);
     const double theta = 0.5 * (hi + lo), aax = 0.5 * (hi - lo), bim = frac * aax;
     const double delta = std::sqrt(std::max(aax * aax - bim * bim, 1e-24)), sigma = theta / delta;
     double rho = 1.0 / sigma;
@@ -1296,6 +1298,8 @@ struct Engine {
       // growth), every 2nd from there on; without history every 4th.
       const int kfine = ch_last[didx] > 0 ? std::max(4, (ch_last[didx] - ch_head - 4) & ~1) : 0;
       static const int fine_step = std::getenv("HDG_CHEB_FINE_STEP") ? std::atoi(std::getenv("HDG_CHEB_FINE_STEP")) : 2;
+      static const double handover_env = std::getenv("HDG_CHEB_HANDOVER") ? std::atof(std::getenv("HDG_CHEB_HANDOVER")) : -1.0;
+      const double handover = handover_env >= 0.0 ? handover_env : ((cfg.degree >= 2 && cfg.tent_precond == 2) ? 0.6 : 0.0);
       const bool check = kfine > 0 ? (k < kfine ? (k % 8 == 0) : ((k - kfine) % fine_step == 0)) : (k % 4 == 0);
       const double rn = 1.0 / (2.0 * sigma - rho);
       adv_apply(cur, qstar, t, gamma, b);
@@ -1333,6 +1337,12 @@ struct Engine {
           const double obs = std::pow(nz / nz_prev, 1.0 / (k - k_prev));
           const double remaining = std::log(rtol * beta0 / nz) / std::log(obs);
           tail = k >= 16 && obs > 0.75 && remaining > 24.0;
+          // Deliberate hand-over (HDG_CHEB_HANDOVER = rate threshold, 0 = off): the iteration on a THIN ellipse takes
+          // the bulk of the spectrum down at 0.25-0.3 per iteration and then crawls on the few eigenvalues with large
+          // imaginary parts that the ellipse leaves out; a GMRES iteration costs 2-3 Chebyshev iterations (Krylov basis
+          // traffic) but removes exactly those.  Hand over as soon as the observed rate is worse than what GMRES buys per
+          // unit of cost, unless the end is a few iterations away anyway.
+          if (handover > 0.0 && k >= 6 && obs > handover && remaining > 6.0) tail = true;
         }
         k_prev = k; nz_prev = nz;
         const bool stalled = tail || stall_checks >= 8 || k > 6 * expected + 64;
@@ -1342,6 +1352,8 @@ struct Engine {
             ch_widen[didx] = std::min(ch_widen[didx] * 1.25, 4.0);  // more generously
           } else if (!tail) {
             ch_slow[didx] = true;  // right interval, slow iteration: GMRES until the periodic re-estimate
+          } else {
+            ch_last[didx] = its;  // the next solve of this stage starts its fine checks shortly before this point
           }
           if (debug_on())
             fprintf(stderr, "[cheb]   falling back to GMRES at k=%d (%s; |Mr| %.2e, best %.2e)\n", k,

@@ -228,8 +228,11 @@ def test_section_timers_across_the_abi(hip_lib):
     sums, cnt = e.iteration_stats()
     e.set_kernel_timing(False)
     n_adv, n_lift = tk["kernel_advection"][0], tk["kernel_lift"][0]
-    assert n_adv > 0 and n_lift > 0 and abs(n_adv - n_lift) <= 2 * cnt[0]
-    assert 0.7 * sums[0] <= n_lift <= sums[0] + 2 * cnt[0], (n_lift, sums, cnt)  # one lift per Chebyshev iteration
+    # one fused lift per Chebyshev iteration; the advection operator in residual form once more per solve and per GMRES
+    # cycle of the finishing phase (k = 2: the Chebyshev iteration hands its tail over to GMRES, whose own launches -- plain
+    # operator, lift without the fused step -- are not the kernels being timed)
+    assert n_adv > 0 and n_lift > 0 and 0 <= n_adv - n_lift <= 4 * cnt[0]
+    assert 0.4 * sums[0] <= n_lift <= sums[0] + 2 * cnt[0], (n_lift, sums, cnt)
     assert 0 < tk["kernel_advection"][1] + tk["kernel_lift"][1] <= tk["tentative_velocity_solve"][1] * 1.001
     e.step()
     assert e.timers(kernels=True)["kernel_advection"][0] == 0  # switched off again
