@@ -1016,7 +1016,7 @@ struct Engine {
   // preconditioned residual norms through *beta_first / *beta_last (beta_last is the Arnoldi estimate).
   int gmres(const double* qstar, double gamma, int didx, const double* b, double* x, double rtol = -1.0,
             int maxit = -1, bool strict = true, std::vector<std::complex<double>>* ritz = nullptr, int m_cycle = 0,
-            double* beta_first = nullptr, double* beta_last = nullptr, double beta0_given = -1.0) {
+            double* beta_first = nullptr, double* beta_last = nullptr, double beta0_given = -1.0, int first_cycle = 4) {
     FlowScope flow_(*this);
     flow_fixed_Q(qstar);
     flow_fixed_Q(b);
@@ -1024,7 +1024,7 @@ struct Engine {
     // adaptive cycle length: short cycles keep the Krylov-basis traffic low (the preconditioned operator
     // is benign: GMRES(4) needs 45.5 iterations where GMRES(30) needs 42.5 at C3); a cycle that reduces
     // the residual by less than 2x doubles the length, up to the configured restart
-    int mcur = std::min(m, 4);
+    int mcur = std::min(m, std::max(1, first_cycle));
     if (ritz) mcur = std::min(m, std::max(1, m_cycle));
     double beta_prev = -1.0;
     std::vector<double> Hraw;
@@ -1259,6 +1259,7 @@ struct Engine {
     const double theta = 0.5 * (hi + lo), aax = 0.5 * (hi - lo), bim = frac * aax;
     const double delta = std::sqrt(std::max(aax * aax - bim * bim, 1e-24)), sigma = theta / delta;
     double rho = 1.0 / sigma;
+
     double* t = wQ2;
     double* z = wQ1;
     const int nvb = vec_blocks(NQ);
@@ -1359,7 +1360,9 @@ struct Engine {
             fprintf(stderr, "[cheb]   falling back to GMRES at k=%d (%s; |Mr| %.2e, best %.2e)\n", k,
                     growing ? "growing" : (tail ? "slow tail" : "stalled"), nz, last);
           finish_in_x();
-          return its + gmres(qstar, gamma, didx, b, x, rtol, cfg.tent_maxit, true, nullptr, 0, nullptr, nullptr, beta0);
+          // the tail after a hand-over is 3-4 decades = 5-7 GMRES iterations: one cycle of 8, no restart in between
+          static const int hand_cycle = std::getenv("HDG_CHEB_HAND_CYCLE") ? std::atoi(std::getenv("HDG_CHEB_HAND_CYCLE")) : 8;
+          return its + gmres(qstar, gamma, didx, b, x, rtol, cfg.tent_maxit, true, nullptr, 0, nullptr, nullptr, beta0, tail ? hand_cycle : 4);
         }
         last = std::min(last, nz);
       }
