@@ -208,11 +208,11 @@ class Engine:
         cfg.gmres_restart = int(kw.get("gmres_restart", 8))
         # hybrid two-level preconditioner Pi + Dinv (I - Pi): one lift kernel per application
         cfg.tent_precond = int(kw.get("tent_precond", 2))
-        # with the hybrid preconditioner GMRES(8) needs 24-43 iterations where the Chebyshev iteration needs
-        # 38-65 (fat, non-real spectrum); Chebyshev still wins in wall time for k <= 2, where the Krylov
-        # basis traffic outweighs the operator (nx = 512, ms/step Chebyshev vs GMRES: k=1 53/67, k=2 80/86,
-        # k=3 232/206, k=4 560/498), see DESIGN.md section 6
-        _cheb_default = 1 if int(kw["degree"]) <= (2 if cfg.tent_precond == 2 else 3) else 0
+        # hybrid preconditioner: Chebyshev on a thin ellipse for the bulk of the spectrum, hand-over of the tail to GMRES
+        # (k >= 2) beats pure GMRES(8) at every degree (512^2, MDOF-updates/s: k=3 252 -> 288,
+        # k=4 184 -> 218) and the fat-ellipse iteration at k = 2 (C3 136.5 -> 118.8 ms/step); the other preconditioners
+        # keep their round-1 choice
+        _cheb_default = 1 if (cfg.tent_precond == 2 or int(kw["degree"]) <= 3) else 0
         cfg.tent_solver = int(kw.get("tent_solver", _cheb_default))
         cfg.trace_rtol = float(kw.get("trace_rtol", 1e-12))
         cfg.trace_maxit = int(kw.get("trace_maxit", 10000))

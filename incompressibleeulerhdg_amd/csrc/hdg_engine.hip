@@ -640,7 +640,10 @@ struct Engine {
     const int ext = lift_ext(in, nullptr, chd_, chx_, c1);
     const Geo gx = g_ext(ext);
     fl.set(out, ext); fl.set(chd_, ext);
-    KTimed kt_(*this, T_KLIFT, fl.active() && ((cfg.tent_solver == 1) == (chd_ != nullptr)));
+    // Chebyshev mode: the lift of an iteration carries the fused step (per-thread kernel) or is the matrix-core kernel
+    // followed by the vector-kernel step; GMRES mode: the plain lift
+    KTimed kt_(*this, T_KLIFT, fl.active() && (cfg.tent_solver == 1 ? (chd_ != nullptr || (use_mfma_lift() && out && !ss))
+                                                                      : chd_ == nullptr));
     if (use_mfma_lift() && out && !chd_ && !ss) {
       // GMRES path at k >= 3: no Chebyshev epilogue -> matrix-core kernel with the packed G tables of this stage
       for (size_t q = 0; q < hybg0.size(); q++)
@@ -1004,6 +1007,11 @@ struct Engine {
     } else if (cfg.tent_precond == 1) {
       bdm_T(r, wQ3);
       bdm_plus_bj(wQ3, zout, r, dinv0[didx], dinv1[didx], d_, x_, c1, c2);
+    } else if (use_mfma_lift()) {
+      // k >= 3: the lift runs on the matrix cores (no fused epilogue there); the Chebyshev step is one vector kernel
+      bdm_hybrid(r, wQ4, hybg0[didx], hybg1[didx]);
+      if (zout) copy(zout, wQ4, NQ);
+      cheb_update(d_, wQ4, x_, c1, c2);
     } else {
       bdm_hybrid(r, zout, hybg0[didx], hybg1[didx], d_, x_, c1, c2, cell_norm ? cell_ss : nullptr);
     }
@@ -1300,12 +1308,13 @@ struct Engine {
       const int kfine = ch_last[didx] > 0 ? std::max(4, (ch_last[didx] - ch_head - 4) & ~1) : 0;
       static const int fine_step = std::getenv("HDG_CHEB_FINE_STEP") ? std::atoi(std::getenv("HDG_CHEB_FINE_STEP")) : 2;
       static const double handover_env = std::getenv("HDG_CHEB_HANDOVER") ? std::atof(std::getenv("HDG_CHEB_HANDOVER")) : -1.0;
-      const double handover = handover_env >= 0.0 ? handover_env : ((cfg.degree >= 2 && cfg.tent_precond == 2) ? 0.6 : 0.0);
+      // k = 2: 0.6; k >= 3 (the operator dominates, a GMRES iteration costs little more than a Chebyshev one): 0.4
+      const double handover = handover_env >= 0.0 ? handover_env : (cfg.tent_precond == 2 ? (cfg.degree >= 3 ? 0.4 : (cfg.degree == 2 ? 0.6 : 0.0)) : 0.0);
       const bool check = kfine > 0 ? (k < kfine ? (k % 8 == 0) : ((k - kfine) % fine_step == 0)) : (k % 4 == 0);
       const double rn = 1.0 / (2.0 * sigma - rho);
       adv_apply(cur, qstar, t, gamma, b);
       // hybrid preconditioner: the lift kernel emits |z_K|^2 per cell (N_c doubles) instead of z (N_Q doubles)
-      const bool cell_norm = check && cfg.tent_precond == 2;
+      const bool cell_norm = check && cfg.tent_precond == 2 && !use_mfma_lift();
       tent_precond_cheb(didx, t, (check && !cell_norm) ? z : nullptr, oth, cur, rn * rho, 2.0 * rn / delta, cell_norm);
       std::swap(cur, oth);
       rho = rn;
