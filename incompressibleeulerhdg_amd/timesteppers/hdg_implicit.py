@@ -19,6 +19,10 @@ class IncompressibleEulerHDGImplicit(IncompressibleEuler):
 
     def __init__(self, mesh, degree, dt, flux="upwind", use_projection_method=True, callbacks=None,
                  n_richardson=None, **engine_options):
+        # the fully implicit step carries the whole dt as implicit weight (four times SSP2(3,3,2)'s a_ii dt): the spectrum
+        # of the tentative-velocity operator is too wide for the Chebyshev iteration to pay at k >= 2 (k = 1 / 2 / 3 at
+        # 256^2 / 512^2 / 512^2, ms per step with tent_solver 0 / 1: 5.17 / 4.31, 10.80 / 11.17, 15.64 / 16.08)
+        engine_options.setdefault("tent_solver", 1 if degree <= 1 else 0)
         super().__init__(mesh, degree, dt, label="HDG Implicit", **engine_options)
         self.flux = flux
         assert self.flux in ["upwind", "centered"]
