@@ -851,24 +851,23 @@ struct Engine {
       int cnt = std::min(MAXV, nv - off);
       const int nout = cnt + (cross ? 1 : 0);
       int nb = std::min(dot_blocks, vec_blocks(n));
-      if (nout <= 4) {
-        // the common case (CG / Chebyshev norms: 1-3 vectors): lean instantiation, 8 accumulator registers
-        VecList<4> vl;
-        for (int q = 0; q < 4; q++) vl.p[q] = q < cnt ? V[off + q] : nullptr;
-        if (big(n)) k_multidot<4, true><<<nb, HDG_DOT_BLOCK, 0, stream>>>(n, w, vl, cnt, d_part, mask_for(kind), cross ? 1 : 0);
-        else k_multidot<4, false><<<nb, HDG_DOT_BLOCK, 0, stream>>>(n, w, vl, cnt, d_part, mask_for(kind), cross ? 1 : 0);
-      } else if (nout <= 6) {
-        // single-reduction CG: 4 vectors + 1 cross product
-        VecList<6> vl;
-        for (int q = 0; q < 6; q++) vl.p[q] = q < cnt ? V[off + q] : nullptr;
-        if (big(n)) k_multidot<6, true><<<nb, HDG_DOT_BLOCK, 0, stream>>>(n, w, vl, cnt, d_part, mask_for(kind), cross ? 1 : 0);
-        else k_multidot<6, false><<<nb, HDG_DOT_BLOCK, 0, stream>>>(n, w, vl, cnt, d_part, mask_for(kind), cross ? 1 : 0);
-      } else {
-        VecList<MAXV> vl;
-        for (int q = 0; q < MAXV; q++) vl.p[q] = q < cnt ? V[off + q] : nullptr;
-        if (big(n)) k_multidot<MAXV, true><<<nb, HDG_DOT_BLOCK, 0, stream>>>(n, w, vl, cnt, d_part, mask_for(kind), cross ? 1 : 0);
-        else k_multidot<MAXV, false><<<nb, HDG_DOT_BLOCK, 0, stream>>>(n, w, vl, cnt, d_part, mask_for(kind), cross ? 1 : 0);
-      }
+      int self = -1;
+      for (int q = 0; q < cnt && self < 0; q++) if (V[off + q] == w) self = q;
+      const int cr = cross ? 1 : 0;
+      const RowMask mk = mask_for(kind);
+      auto launch = [&](auto tag) {
+        constexpr int MV = decltype(tag)::value;
+        VecList<MV> vl;
+        for (int q = 0; q < MV; q++) vl.p[q] = q < cnt ? V[off + q] : nullptr;
+        if (big(n)) k_multidot<MV, true><<<nb, HDG_DOT_BLOCK, 0, stream>>>(n, w, vl, cnt, d_part, mk, cr, self);
+        else k_multidot<MV, false><<<nb, HDG_DOT_BLOCK, 0, stream>>>(n, w, vl, cnt, d_part, mk, cr, self);
+      };
+      // lean instantiations by output count: <= 4 (norms, CG of round 1, early Gram-Schmidt passes), <= 6 (single-reduction
+      // CG: 4 vectors + 1 cross product), <= 12 (the rest of a GMRES(8) cycle); the 32-wide one only beyond that
+      if (nout <= 4) launch(std::integral_constant<int, 4>{});
+      else if (nout <= 6) launch(std::integral_constant<int, 6>{});
+      else if (nout <= 12) launch(std::integral_constant<int, 12>{});
+      else launch(std::integral_constant<int, MAXV>{});
       k_reduce_parts<<<nout, 256, 0, stream>>>(nb, nout, d_part, d_res);
       comm->allreduce_sum(d_res, nout, stream);
       n_reduce++;

@@ -1868,6 +1868,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 // partial dots of w against nv vectors V[k] (k < nv <= MAXV): part[block*nvo + k]; deterministic.
+// self >= 0: V[self] is w itself and is not loaded a second time
 // cross != 0 (nv >= 2, nv < MAXV): one more result, (V[0], V[1]), from the values already loaded; nvo = nv + cross
 #define HDG_DOT_BLOCK 256
 // entries outside the rows [lo, hi] of the (ghosted) row structure are skipped: every dot product
@@ -1889,7 +1890,7 @@ struct VecList {
 template <int MAXV, bool NT>
 __global__ __launch_bounds__(HDG_DOT_BLOCK) void k_multidot(long N, const double* __restrict__ w,
                                                              const VecList<MAXV> V, int nv,
-                                                             double* __restrict__ part, RowMask mk, int cross) {
+                                                             double* __restrict__ part, RowMask mk, int cross, int self = -1) {
   __shared__ double sm[HDG_DOT_BLOCK / 64][MAXV];
   double acc[MAXV];
   double accx = 0.0;  // cross product (own register: a runtime index into acc[] would demote it to scratch)
@@ -1915,8 +1916,9 @@ __global__ __launch_bounds__(HDG_DOT_BLOCK) void k_multidot(long N, const double
       }
       const hdg_d2 t = ldv<NT>(w, i);
       wv[u] = hdg_d2{t.x * m0, t.y * m1};
+      // self: V[self] IS w (norms, the (w, w) entry of a Gram-Schmidt pass): its values are already here
 #pragma unroll
-      for (int k = 0; k < MAXV; k++) vv[u][k] = (k < nv) ? ldv<NT>(V.p[k], i) : hdg_d2{0.0, 0.0};
+      for (int k = 0; k < MAXV; k++) vv[u][k] = (k < nv) ? (k == self ? t : ldv<NT>(V.p[k], i)) : hdg_d2{0.0, 0.0};
     }
 #pragma unroll
     for (int u = 0; u < U; u++) {
