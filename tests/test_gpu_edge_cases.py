@@ -244,3 +244,32 @@ def test_section_timers_across_the_abi(hip_lib):
     out = buf.getvalue()
     for label in ("timestep", "bdm_projection", "tentative_velocity_solve", "pressure_solve"):
         assert label in out, out
+
+
+def test_bench_line_contract(hip_lib):
+    """`python bench.py` prints ONE JSON line with the driver's keys, the roofline block (durations measured in place for
+    the two kernels of a tentative-velocity iteration) and, unless switched off, the CPU baseline with the reference's
+    timer labels; run here on a small mesh (the schema does not depend on the size)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for k, extra in ((2, ["--no-cpu-baseline"]), (3, ["--no-cpu-baseline"])):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--nx", "64", "--degree", str(k), "--steps", "2", "--warmup", "1"] + extra,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert r.returncode == 0, r.stderr.decode()[-3000:]
+        lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+        assert len(lines) == 1
+        d = json.loads(lines[0])
+        for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                    "dtype", "data", "config", "roofline", "timers"):
+            assert key in d, key
+        assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["dtype"] == "f64" and d["vs_baseline"] is None
+        assert d["unit"] == "million DOF-updates/s" and d["value"] > 0 and abs(d["value"] - d["config"]["n_dof"] * 2 / (d["ms_per_step"] * 2e-3) / 1e6) < 1e-6 * d["value"]
+        rf = d["roofline"]
+        assert rf["bound"] == ("hbm" if k <= 2 else "mfma") and rf["unit"] == ("GB/s" if k <= 2 else "TFLOP/s")
+        assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["launches_timed"] > 0 and rf["timing"].startswith("in place")
+        assert set(d["timers"]) >= {"timestep", "tentative_velocity_solve", "pressure_solve", "bdm_projection"}
+        assert d["timers"]["timestep"]["ncall"] == 2
