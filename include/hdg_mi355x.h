@@ -106,6 +106,10 @@ const char* hdg_last_error(const hdg_handle* h); /* h may be NULL for create err
 #define HDG_COMM_SHM 2
 int hdg_create_distributed(const hdg_config* cfg, int rank, int nranks, int backend, const char* token, hdg_handle** out);
 int hdg_rccl_unique_id(char* out128);
+/* One-GPU self-test of the RCCL transport (no reference counterpart): a 1-rank communicator runs the grouped send / recv
+ * pattern of a halo exchange with itself as both neighbours, an all-reduce and an all-gather of n doubles each;
+ * *max_err = largest deviation from the expected buffer contents (0 when everything arrived). */
+int hdg_rccl_selftest(int device, int n, double* max_err);
 
 /* sizes of this rank's strip: n_cells, n_edges, n_u, n_p, n_l */
 int hdg_get_sizes(const hdg_handle* h, long* n_cells, long* n_edges, int* n_u, int* n_p, int* n_l);

@@ -119,6 +119,7 @@ SIGNATURES = {
     "hdg_run_separable": [_h, C.c_int, _dp],
     "hdg_implicit_step": [_h, _ip, _ip],
     "hdg_get_iteration_stats": [_h, _dp, _lp, C.c_int],
+    "hdg_rccl_selftest": [C.c_int, C.c_int, _dp],
     "hdg_get_timers": [_h, _dp, _dp, _lp, C.c_int],
     "hdg_set_kernel_timing": [_h, C.c_int],
     "hdg_set_tracer": [_h, _dp],

@@ -81,6 +81,16 @@ struct CommRccl : Comm {
     }
     ck(ncclGroupEnd(), "ncclGroupEnd");
   }
+  // self-test only (hdg_rccl_selftest): the grouped send / recv pattern of exchange() with THIS rank as both neighbours
+  // (RCCL matches sends and receives between the same pair of ranks in call order: slo -> rlo, shi -> rhi)
+  void exchange_loopback(const double* slo, double* rlo, const double* shi, double* rhi, size_t n, hipStream_t st) {
+    ck(ncclGroupStart(), "ncclGroupStart");
+    ck(ncclSend(slo, n, ncclDouble, rank, comm, st), "ncclSend");
+    ck(ncclRecv(rlo, n, ncclDouble, rank, comm, st), "ncclRecv");
+    ck(ncclSend(shi, n, ncclDouble, rank, comm, st), "ncclSend");
+    ck(ncclRecv(rhi, n, ncclDouble, rank, comm, st), "ncclRecv");
+    ck(ncclGroupEnd(), "ncclGroupEnd");
+  }
   void allreduce_sum(double* dev, int n, hipStream_t st) override {
     ck(ncclAllReduce(dev, dev, n, ncclDouble, ncclSum, comm, st), "ncclAllReduce");
   }

@@ -2519,6 +2519,49 @@ int hdg_rccl_unique_id(char* out128) {
   std::memcpy(out128, &id, sizeof(id) < 128 ? sizeof(id) : 128);
   return HDG_OK;
 }
+// One-GPU self-test of the RCCL transport (the multi-rank send / recv path cannot run on a box with one GPU: RCCL refuses two
+// ranks on one device): a 1-rank communicator runs the grouped ncclSend / ncclRecv pattern of Comm::exchange with itself as
+// both neighbours, an all-reduce and an all-gather on the given stream-ordered buffers of n doubles; *max_err = largest
+// deviation from the expected contents.
+int hdg_rccl_selftest(int device, int n, double* max_err) {
+  if (n < 1 || !max_err) return HDG_ERR_ARG;
+  *max_err = -1.0;
+  try {
+    if (hipSetDevice(device) != hipSuccess) { g_create_error = "hipSetDevice failed (no GPU?)"; return HDG_ERR_HIP; }
+    ncclUniqueId id;
+    if (ncclGetUniqueId(&id) != ncclSuccess) { g_create_error = "ncclGetUniqueId failed"; return HDG_ERR_COMM; }
+    hdg::CommRccl comm(0, 1, reinterpret_cast<const char*>(&id));
+    hipStream_t st;
+    if (hipStreamCreate(&st) != hipSuccess) throw hdg::HipError{"hipStreamCreate failed"};
+    std::vector<double> a(n), b(n), out(4 * (size_t)n);
+    for (int i = 0; i < n; i++) { a[i] = 1.0 + i; b[i] = -2.0 * i - 0.5; }
+    double* d = nullptr;
+    if (hipMalloc((void**)&d, sizeof(double) * 6 * (size_t)n) != hipSuccess) throw hdg::HipError{"hipMalloc failed"};
+    double *slo = d, *shi = d + n, *rlo = d + 2 * (size_t)n, *rhi = d + 3 * (size_t)n, *red = d + 4 * (size_t)n, *gat = d + 5 * (size_t)n;
+    (void)hipMemcpyAsync(slo, a.data(), sizeof(double) * n, hipMemcpyHostToDevice, st);
+    (void)hipMemcpyAsync(shi, b.data(), sizeof(double) * n, hipMemcpyHostToDevice, st);
+    (void)hipMemsetAsync(rlo, 0, sizeof(double) * 4 * (size_t)n, st);
+    comm.exchange_loopback(slo, rlo, shi, rhi, (size_t)n, st);
+    (void)hipMemcpyAsync(red, slo, sizeof(double) * n, hipMemcpyDeviceToDevice, st);
+    comm.allreduce_sum(red, n, st);
+    comm.allgather(shi, gat, (size_t)n, st);
+    (void)hipMemcpyAsync(out.data(), rlo, sizeof(double) * 4 * (size_t)n, hipMemcpyDeviceToHost, st);
+    if (hipStreamSynchronize(st) != hipSuccess) throw hdg::HipError{"hipStreamSynchronize failed"};
+    double err = 0.0;
+    for (int i = 0; i < n; i++) {
+      err = std::max(err, std::fabs(out[i] - a[i]));                        // rlo <- slo
+      err = std::max(err, std::fabs(out[(size_t)n + i] - b[i]));            // rhi <- shi
+      err = std::max(err, std::fabs(out[2 * (size_t)n + i] - a[i]));        // all-reduce over one rank
+      err = std::max(err, std::fabs(out[3 * (size_t)n + i] - b[i]));        // all-gather of one block
+    }
+    *max_err = err;
+    (void)hipFree(d);
+    (void)hipStreamDestroy(st);
+    return HDG_OK;
+  } catch (const hdg::HipError& e) { g_create_error = e.msg; return HDG_ERR_HIP;
+  } catch (const hdg::CommError& e) { g_create_error = e.msg; return HDG_ERR_COMM;
+  } catch (...) { g_create_error = "unknown error"; return HDG_ERR_ARG; }
+}
 static int create_impl(const hdg_config* cfg, int rank, int nranks, int backend, const char* token, hdg_handle** out) {
   if (!cfg || !out || nranks < 1 || rank < 0 || rank >= nranks) return HDG_ERR_ARG;
   *out = nullptr;

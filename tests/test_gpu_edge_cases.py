@@ -273,3 +273,20 @@ def test_bench_line_contract(hip_lib):
         assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["launches_timed"] > 0 and rf["timing"].startswith("in place")
         assert set(d["timers"]) >= {"timestep", "tentative_velocity_solve", "pressure_solve", "bdm_projection"}
         assert d["timers"]["timestep"]["ncall"] == 2
+
+
+def test_rccl_selftest_loopback(hip_lib):
+    """hdg_rccl_selftest: the grouped ncclSend / ncclRecv pattern of a halo exchange (with this rank as both neighbours), an
+    all-reduce and an all-gather on a 1-rank RCCL communicator -- the part of the RCCL transport a one-GPU box can run
+    (two ranks on one device are refused by RCCL; the multi-rank logic is covered by the shared-memory transport)."""
+    import ctypes as C
+
+    from incompressibleeulerhdg_amd import _lib
+
+    lib = _lib.load_library()
+    for n in (1, 1000, 1 << 20):
+        err = C.c_double(-1.0)
+        rc = lib.hdg_rccl_selftest(0, n, C.byref(err))
+        assert rc == 0, lib.hdg_last_error(None).decode()
+        assert err.value == 0.0, (n, err.value)
+    assert lib.hdg_rccl_selftest(0, 0, C.byref(err)) != 0
