@@ -27,11 +27,14 @@ for K in 3 4; do
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/k${K}_write -o w -- $B --degree $K --nx 512 --steps 2 --warmup 1 > $O/k${K}_write.log 2>&1
 done
 cd $R
-python3 bench.py > $O/bench_c3.json 2> $O/bench_c3.err
-python3 bench.py --degree 3 --nx 512 --no-cpu-baseline > $O/bench_k3.json 2> $O/bench_k3.err
-python3 bench.py --degree 4 --nx 512 --no-cpu-baseline > $O/bench_k4.json 2> $O/bench_k4.err
 # summarise here: the raw counter / trace CSVs are larger than what gpurun copies back
-python3 tools/summarise_profiles.py $TAG $R/gpurun_out/summary_$TAG > $R/gpurun_out/summary_$TAG.log 2>&1
+S=$R/gpurun_out/summary_$TAG
+python3 tools/summarise_profiles.py $TAG $S > $R/gpurun_out/summary_$TAG.log 2>&1
 tail -25 $R/gpurun_out/summary_$TAG.log
 rm -rf $O
-ls $R/gpurun_out/summary_$TAG
+# the bench lines of the same build, with roofline.traffic from the file just written (same source hash)
+cp $S/pmc_traffic.json $R/profiles/pmc_traffic.json
+python3 bench.py > $S/${TAG}_bench_c3.json 2> $R/gpurun_out/bench_c3_$TAG.err
+python3 bench.py --degree 3 --nx 512 --no-cpu-baseline > $S/${TAG}_bench_k3.json 2> $R/gpurun_out/bench_k3_$TAG.err
+python3 bench.py --degree 4 --nx 512 --no-cpu-baseline > $S/${TAG}_bench_k4.json 2> $R/gpurun_out/bench_k4_$TAG.err
+ls $S
