@@ -2568,4 +2568,33 @@ __global__ void k_unpack_rows(double* __restrict__ v, long plane_stride, int row
   }
 }
 
+// Self-check of the ghost-row bookkeeping (HDG_FLOW_CHECK): compare received neighbour rows with the ghost rows in place;
+// out[0] = max |ghost - received|, out[1] = max |received| (non-negative doubles order like their bit patterns)
+__global__ void k_compare_rows(const double* __restrict__ v, long plane_stride, int row_len, int nplanes, int depth, int row_lo,
+                               int row_hi, const double* __restrict__ buf_lo, const double* __restrict__ buf_hi,
+                               unsigned long long* __restrict__ out) {
+  const int row = blockIdx.y == 0 ? row_lo : row_hi;
+  if (row < 0) return;
+  const double* __restrict__ buf = blockIdx.y == 0 ? buf_lo : buf_hi;
+  const long chunk = (long)depth * row_len;
+  const long n = (long)nplanes * chunk;
+  const long stride = (long)gridDim.x * blockDim.x;
+  double dmax = 0.0, amax = 0.0;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += stride) {
+    const long pl = idx / chunk;
+    const double a = v[pl * plane_stride + (long)row * row_len + (idx - pl * chunk)], b = buf[idx];
+    const double d = fabs(a - b);
+    dmax = (d == d) ? fmax(dmax, d) : 1e300;  // a NaN on either side counts as a mismatch
+    amax = fmax(amax, fabs(b));
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    dmax = fmax(dmax, __shfl_down(dmax, off, 64));
+    amax = fmax(amax, __shfl_down(amax, off, 64));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMax(out, (unsigned long long)__double_as_longlong(dmax));
+    atomicMax(out + 1, (unsigned long long)__double_as_longlong(amax));
+  }
+}
+
 }  // namespace hdg

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _run_ranks(nranks, k, nx, nsteps, tmp_path, extra=()):
+def _run_ranks(nranks, k, nx, nsteps, tmp_path, extra=(), env=None, want_logs=False):
     token = "/hdg_test_" + uuid.uuid4().hex[:12]
     procs, outs = [], []
     for r in range(nranks):
@@ -21,7 +21,7 @@ def _run_ranks(nranks, k, nx, nsteps, tmp_path, extra=()):
         outs.append(out)
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "mp_strip_worker.py"), str(r), str(nranks), token,
                                        str(k), str(nx), str(nsteps), out, *extra],
-                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=dict(os.environ, **(env or {}))))
     logs = []
     for pr in procs:
         try:
@@ -33,6 +33,8 @@ def _run_ranks(nranks, k, nx, nsteps, tmp_path, extra=()):
         logs.append(o.decode(errors="replace"))
     for r, pr in enumerate(procs):
         assert pr.returncode == 0, f"rank {r} failed:\n{logs[r][-3000:]}"
+    if want_logs:
+        return [np.load(o) for o in outs], logs
     return [np.load(o) for o in outs]
 
 
@@ -112,6 +114,21 @@ def test_strip_partition_with_the_other_solver_paths(hip_lib, tmp_path, nranks, 
     lam1 = ts._engine.get_field(_lib.HDG_STATE_CURRENT, Q=False, p=False)[2]
     rel = lambda a, b: np.max(np.abs(a - b)) / np.max(np.abs(b))
     assert rel(Q, Q1.dat.data) < 2e-8 and rel(p, p1.dat.data) < 2e-8 and rel(lam, lam1) < 2e-8
+
+
+@pytest.mark.parametrize("nranks,k,nx,opts", [(2, 2, 16, {}), (4, 1, 16, {}), (2, 3, 40, {}), (2, 1, 128, {}), (2, 2, 16, {"tent_solver": 0}),
+                                              (3, 2, 12, {"tent_precond": 1}), (2, 4, 16, {})])
+def test_ghost_row_bookkeeping_self_check(hip_lib, tmp_path, nranks, k, nx, opts):
+    """HDG_FLOW_CHECK: every exchange the bookkeeping (Engine::Flow) skips is carried out anyway and the received rows are
+    compared with the ghost rows in place; a solver call fails if they differ by more than 1e-9 relative.  The rows a rank
+    computes redundantly agree with its neighbour's to rounding (here: exactly), a stale validity would be an O(1) error."""
+    import re
+
+    parts, logs = _run_ranks(nranks, k, nx, 2, tmp_path, extra=tuple(f"opt:{a}={b}" for a, b in opts.items()),
+                             env={"HDG_FLOW_CHECK": "1", "HDG_DEBUG": "1"}, want_logs=True)
+    m = re.search(r"\[flow check\] (\d+) skipped exchanges verified, worst relative deviation ([0-9.eE+-]+)", logs[0])
+    assert m, logs[0][-2000:]
+    assert int(m.group(1)) > 20 and float(m.group(2)) < 1e-12, m.group(0)
 
 
 def test_strip_partition_unsplit(hip_lib, tmp_path):

@@ -12,7 +12,7 @@ for r, p in enumerate(procs):
     o, _ = p.communicate(timeout=600)
     txt = o.decode(errors="replace")
     for line in txt.splitlines():
-        if line.startswith("[comm]"):
+        if line.startswith("[comm]") or line.startswith("[flow check]"):
             print(f"k={k} nx={nx} steps={nsteps}:", line)
     if p.returncode != 0:
         print("rank", r, "failed", txt[-1500:])
