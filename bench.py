@@ -96,7 +96,7 @@ FP64_MATRIX_PEAK_TF = 78.6  # MI355X FP64 matrix = FP64 vector peak (AMD datashe
 
 def roofline_block(eng, args, nx, k, world, ktimers=None):
     """Roofline of the dominant kernel.  Durations of the two kernels of a tentative-velocity iteration: HIP-event
-    brackets around every launch inside one extra step (`ktimers`, hdg_set_kernel_timing; `timing: "in place"`), for
+    brackets around every launch of the timed steps (`ktimers`, hdg_set_kernel_timing; `timing: "in place"`), for
     the other kernels a stand-alone launch loop on the engine's stream (hdg_time_kernel).
 
     An iteration of the tentative-velocity solve (55-60 % of the step) is two launches: the advection operator and
@@ -160,7 +160,7 @@ def roofline_block(eng, args, nx, k, world, ktimers=None):
                                     traffic=pmc.get(oth), launches_timed=nl[oth], ms_stand_alone=alone[oth])
         return dict(bound="hbm", kernel=dname, achieved=gbs(dbytes, dms), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=gbs(dbytes, dms) / HBM_PEAK_GBS, traffic=pmc.get(dom), algorithmic_bytes=dbytes, ms_per_launch=dms,
-                    timing="in place: HIP-event pair around each launch inside one extra step" if nl[dom] else "stand-alone launch loop",
+                    timing="in place: HIP-event pair around each launch of the timed steps" if nl[dom] else "stand-alone launch loop",
                     launches_timed=nl[dom], ms_stand_alone=alone[dom],
                     stream_triad_GBs=triad, frac_of_triad=gbs(dbytes, dms) / triad, other_kernels=others)
     # matrix-core kernels (k >= 3)
@@ -187,7 +187,7 @@ def roofline_block(eng, args, nx, k, world, ktimers=None):
                 frac=tf(adv_alg, ms_adv) / FP64_MATRIX_PEAK_TF, mfma_util=tf(adv_issued, ms_adv) / FP64_MATRIX_PEAK_TF,
                 mfma_busy_pmc=pmc_mfma.get("adv"),  # SQ_VALU_MFMA_BUSY_CYCLES / (kernel cycles x 1024 SIMDs), profiles/pmc_traffic.json
                 algorithmic_flops=adv_alg, issued_mfma_flops=adv_issued, ms_per_launch=ms_adv, traffic=pmc.get("adv"),
-                timing="in place: HIP-event pair around each launch inside one extra step" if n_adv else "stand-alone launch loop",
+                timing="in place: HIP-event pair around each launch of the timed steps" if n_adv else "stand-alone launch loop",
                 launches_timed=n_adv, ms_stand_alone=ms_adv_alone,
                 hbm_GBs=gbs(8.0 * 3 * NQ, ms_adv), algorithmic_bytes=8.0 * 3 * NQ, stream_triad_GBs=triad, other_kernels=others)
 
@@ -345,6 +345,12 @@ def main():
         eng.run_separable(ssp2_scales(args.warmup, dt, kappa))
     eng.iteration_stats(reset=True)
     eng.timers(reset=True)
+    # every launch of the two kernels of a tentative-velocity iteration is bracketed by its own HIP-event pair on the
+    # engine's stream DURING the timed steps (hdg_set_kernel_timing: in place, with the operands and cache state of the
+    # solve); the roofline block divides by these durations.  Cost: two event records per launch, < 0.5 % of a step
+    # (BENCH_KERNEL_TIMING=extra moves the brackets to one extra step after the timed region instead).
+    ktiming_extra = os.environ.get("BENCH_KERNEL_TIMING") == "extra"
+    eng.set_kernel_timing(not ktiming_extra)
     sync_barrier()
     t0 = time.perf_counter()
     eng.run_separable(ssp2_scales(args.steps, dt, kappa, t0=args.warmup * dt))  # synchronous on return
@@ -353,13 +359,14 @@ def main():
     if dist is not None:
         elapsed = reduce_scalar(elapsed, dist.ReduceOp.MAX)
     sums, cnt = eng.iteration_stats()
-    timers_raw = eng.timers(reset=True)
-    # one more step, OUTSIDE the timed region, with every launch of the two kernels of a tentative-velocity iteration
-    # bracketed by its own event pair on the engine's stream (hdg_set_kernel_timing): the roofline block divides by
-    # durations measured in place -- the operands and cache state of the solve -- not by a stand-alone launch loop
-    eng.set_kernel_timing(True)
-    eng.run_separable(ssp2_scales(1, dt, kappa, t0=(args.warmup + args.steps) * dt))
-    ktimers = {lab: (n, tot) for lab, (n, tot, _) in eng.timers(reset=True, kernels=True).items() if lab.startswith("kernel_")}
+    timers_raw = eng.timers(reset=ktiming_extra, kernels=True)
+    if ktiming_extra:
+        eng.set_kernel_timing(True)
+        eng.run_separable(ssp2_scales(1, dt, kappa, t0=(args.warmup + args.steps) * dt))
+        ktimers = {lab: (n, tot) for lab, (n, tot, _) in eng.timers(reset=True, kernels=True).items() if lab.startswith("kernel_")}
+    else:
+        ktimers = {lab: (n, tot) for lab, (n, tot, _) in timers_raw.items() if lab.startswith("kernel_")}
+    timers_raw = {lab: v for lab, v in timers_raw.items() if not lab.startswith("kernel_")}
     eng.set_kernel_timing(False)
 
     if rank == 0:

@@ -176,7 +176,7 @@ int hdg_get_timers(hdg_handle* h, double* total_ms, double* sumsq_ms, long* ncal
  * kernels of a tentative-velocity iteration -- 5: advection operator (k <= 2: residual form b - (I - gamma F) x of the
  * Chebyshev iteration; k >= 3: the plain operator GMRES applies), 6: hybrid edge-lift preconditioner (with the fused
  * Chebyshev step / plain) -- bracketed by its own event pair IN PLACE, i.e. with the operands and cache state of the
- * solve.  Recorded only while switched on (two event records per launch). */
+ * solve.  Recorded only while switched on (two event records per launch: about 1 % of a C3 step). */
 int hdg_set_kernel_timing(hdg_handle* h, int on);
 
 /* ---- passive tracer.  Explicit DG transport of a scalar in DG_k by the L2 projection of
