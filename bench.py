@@ -94,7 +94,7 @@ def self_launch(args, argv):
 FP64_MATRIX_PEAK_TF = 78.6  # MI355X FP64 matrix = FP64 vector peak (AMD datasheet; the guide's MFMA table has no FP64 row)
 
 
-def roofline_block(eng, args, nx, k, world, ktimers=None):
+def roofline_block(eng, args, nx, k, world, ktimers=None, timed_where="the timed steps"):
     """Roofline of the dominant kernel.  Durations of the two kernels of a tentative-velocity iteration: HIP-event
     brackets around every launch of the timed steps (`ktimers`, hdg_set_kernel_timing; `timing: "in place"`), for
     the other kernels a stand-alone launch loop on the engine's stream (hdg_time_kernel).
@@ -160,7 +160,7 @@ def roofline_block(eng, args, nx, k, world, ktimers=None):
                                     traffic=pmc.get(oth), launches_timed=nl[oth], ms_stand_alone=alone[oth])
         return dict(bound="hbm", kernel=dname, achieved=gbs(dbytes, dms), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=gbs(dbytes, dms) / HBM_PEAK_GBS, traffic=pmc.get(dom), algorithmic_bytes=dbytes, ms_per_launch=dms,
-                    timing="in place: HIP-event pair around each launch of the timed steps" if nl[dom] else "stand-alone launch loop",
+                    timing=("in place: HIP-event pair around each launch of " + timed_where) if nl[dom] else "stand-alone launch loop",
                     launches_timed=nl[dom], ms_stand_alone=alone[dom],
                     stream_triad_GBs=triad, frac_of_triad=gbs(dbytes, dms) / triad, other_kernels=others)
     # matrix-core kernels (k >= 3)
@@ -187,7 +187,7 @@ def roofline_block(eng, args, nx, k, world, ktimers=None):
                 frac=tf(adv_alg, ms_adv) / FP64_MATRIX_PEAK_TF, mfma_util=tf(adv_issued, ms_adv) / FP64_MATRIX_PEAK_TF,
                 mfma_busy_pmc=pmc_mfma.get("adv"),  # SQ_VALU_MFMA_BUSY_CYCLES / (kernel cycles x 1024 SIMDs), profiles/pmc_traffic.json
                 algorithmic_flops=adv_alg, issued_mfma_flops=adv_issued, ms_per_launch=ms_adv, traffic=pmc.get("adv"),
-                timing="in place: HIP-event pair around each launch of the timed steps" if n_adv else "stand-alone launch loop",
+                timing=("in place: HIP-event pair around each launch of " + timed_where) if n_adv else "stand-alone launch loop",
                 launches_timed=n_adv, ms_stand_alone=ms_adv_alone,
                 hbm_GBs=gbs(8.0 * 3 * NQ, ms_adv), algorithmic_bytes=8.0 * 3 * NQ, stream_triad_GBs=triad, other_kernels=others)
 
@@ -349,7 +349,9 @@ def main():
     # engine's stream DURING the timed steps (hdg_set_kernel_timing: in place, with the operands and cache state of the
     # solve); the roofline block divides by these durations.  Cost: two event records per launch, < 0.5 % of a step
     # (BENCH_KERNEL_TIMING=extra moves the brackets to one extra step after the timed region instead).
-    ktiming_extra = os.environ.get("BENCH_KERNEL_TIMING") == "extra"
+    # Small problems (kernels of 5-20 us: C2) would be perturbed by the brackets themselves (+15 % per step measured at
+    # k = 1, 256^2): there, and on request, the brackets go to one extra step after the timed region.
+    ktiming_extra = os.environ.get("BENCH_KERNEL_TIMING", "timed" if nx >= 512 else "extra") == "extra"
     eng.set_kernel_timing(not ktiming_extra)
     sync_barrier()
     t0 = time.perf_counter()
@@ -377,7 +379,7 @@ def main():
         # device-side section timers of the timed steps (labels of the reference's PerformanceLog)
         timers = {lab: dict(ncall=n, total_ms=tot * 1e3, avg_ms=(tot / n * 1e3 if n else 0.0))
                   for lab, (n, tot, _) in timers_raw.items() if n}
-        roof = roofline_block(eng, args, nx, k, world, ktimers)
+        roof = roofline_block(eng, args, nx, k, world, ktimers, "one extra step after the timed region" if ktiming_extra else "the timed steps")
         line = {
             "metric": "million DOF-updates/sec (HDG-IMEX k=2, 1024^2 tri mesh)" if (nx, k) == (1024, 2)
             else f"million DOF-updates/sec (HDG-IMEX k={k}, {nx}^2 tri mesh)",

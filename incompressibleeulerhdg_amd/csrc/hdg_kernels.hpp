@@ -1121,37 +1121,37 @@ __device__ __forceinline__ void trace_stencil(const Geo& g, const DevTables& T, 
   for (int m = 0; m < NL; m++) yH[m] = yV[m] = yD[m] = 0.0;
   const double* __restrict__ SL = T.SK[0];
   const double* __restrict__ SU = T.SK[1];
-  if (in_x) load_tr<NL>(lam, g, 0, o, own); else { for (int m = 0; m < NL; m++) own[m] = 0.0; }
-  if (in_x && in_y) load_tr<NL>(lam, g, 2, o, own + NL); else { for (int m = 0; m < NL; m++) own[NL + m] = 0.0; }
-  if (in_y) load_tr<NL>(lam, g, 1, o, own + 2 * NL); else { for (int m = 0; m < NL; m++) own[2 * NL + m] = 0.0; }
-  if (in_x && in_y) {  // L(i,j): all three rows
+  // All loads first, unconditionally (ghost rows and the row padding make every address below a valid one; what a
+  // missing cell would have contributed is simply not used): inside the branches each load waited for its own
+  // predicate and the four cell blocks ran one after the other at memory latency.
+  const bool vL = in_x && in_y, vB = in_x && below, vW = in_y && left;
+  double uA[NT], uB[NT], uC[NT];
+  load_tr<NL>(lam, g, 0, o, own);
+  load_tr<NL>(lam, g, 2, o, own + NL);
+  load_tr<NL>(lam, g, 1, o, own + 2 * NL);
+  load_tr<NL>(lam, g, 0, o + g.P, uA);            // U(i,j):   H(i,j+1)
+  load_tr<NL>(lam, g, 1, oR, uA + 2 * NL);        //           V(i+1,j)
+  load_tr<NL>(lam, g, 2, o - g.P, uB + NL);       // U(i,j-1): D(i,j-1)
+  load_tr<NL>(lam, g, 1, oR - g.P, uB + 2 * NL);  //           V(i+1,j-1)
+  load_tr<NL>(lam, g, 0, oL + g.P, uC);           // U(i-1,j): H(i-1,j+1)
+  load_tr<NL>(lam, g, 2, oL, uC + NL);            //           D(i-1,j)
+#pragma unroll
+  for (int m = 0; m < NL; m++) {
+    if (!in_x) own[m] = 0.0;
+    if (!vL) own[NL + m] = 0.0;
+    if (!in_y) own[2 * NL + m] = 0.0;
+    uA[NL + m] = own[NL + m];
+    uB[m] = own[m];
+    uC[2 * NL + m] = own[2 * NL + m];
+  }
+  if (vL) {  // L(i,j): all three rows;  U(i,j): edges (H(i,j+1), D(i,j), V(i+1,j)), row block e1 -> D
     mv_acc_ld<NL, NT>(SL + 0 * NL * NT, NT, own, yH, -1.0);
     mv_acc_ld<NL, NT>(SL + 1 * NL * NT, NT, own, yD, -1.0);
     mv_acc_ld<NL, NT>(SL + 2 * NL * NT, NT, own, yV, -1.0);
-    // U(i,j): edges (H(i,j+1), D(i,j), V(i+1,j)), row block e1 -> D
-    double u[NT];
-    load_tr<NL>(lam, g, 0, o + g.P, u);
-#pragma unroll
-    for (int m = 0; m < NL; m++) u[NL + m] = own[NL + m];
-    load_tr<NL>(lam, g, 1, oR, u + 2 * NL);
-    mv_acc_ld<NL, NT>(SU + 1 * NL * NT, NT, u, yD, -1.0);
+    mv_acc_ld<NL, NT>(SU + 1 * NL * NT, NT, uA, yD, -1.0);
   }
-  if (in_x && below) {  // U(i,j-1): edges (H(i,j), D(i,j-1), V(i+1,j-1)), row block e0 -> H
-    double u[NT];
-#pragma unroll
-    for (int m = 0; m < NL; m++) u[m] = own[m];
-    load_tr<NL>(lam, g, 2, o - g.P, u + NL);
-    load_tr<NL>(lam, g, 1, oR - g.P, u + 2 * NL);
-    mv_acc_ld<NL, NT>(SU + 0 * NL * NT, NT, u, yH, -1.0);
-  }
-  if (in_y && left) {  // U(i-1,j): edges (H(i-1,j+1), D(i-1,j), V(i,j)), row block e2 -> V
-    double u[NT];
-    load_tr<NL>(lam, g, 0, oL + g.P, u);
-    load_tr<NL>(lam, g, 2, oL, u + NL);
-#pragma unroll
-    for (int m = 0; m < NL; m++) u[2 * NL + m] = own[2 * NL + m];
-    mv_acc_ld<NL, NT>(SU + 2 * NL * NT, NT, u, yV, -1.0);
-  }
+  if (vB) mv_acc_ld<NL, NT>(SU + 0 * NL * NT, NT, uB, yH, -1.0);  // U(i,j-1): edges (H(i,j), D(i,j-1), V(i+1,j-1)), row block e0 -> H
+  if (vW) mv_acc_ld<NL, NT>(SU + 2 * NL * NT, NT, uC, yV, -1.0);  // U(i-1,j): edges (H(i-1,j+1), D(i-1,j), V(i,j)), row block e2 -> V
 }
 
 // K6  trace apply (condensed Schur operator of firedrake.SCPC, hdg_imex.py:128-135), SPD form:
