@@ -1,3 +1,4 @@
+# builds: e.g.  for v in ADV_NT=6 LIFT_NT=3 ADV_PIPE=0; do hipcc -O3 --offload-arch=gfx950 -std=c++17 -shared -fPIC -DHDG_$v -o build/var/lib_${v/=/_}.so incompressibleeulerhdg_amd/csrc/hdg_engine.hip -L/opt/rocm/lib -lrccl -lrt -lpthread; done
 for v in default ADV_NT_6 ADV_NT_5 ADV_NT_3 LIFT_NT_6 LIFT_NT_5 LIFT_NT_3 ADV_PIPE_0 default; do
   if [ $v = default ]; then unset HDG_LIB_PATH; else export HDG_LIB_PATH=$PWD/build/var/lib_$v.so; fi
   python bench.py --steps 6 --warmup 2 --no-cpu-baseline > gpurun_out/var.json 2>/dev/null
