@@ -131,6 +131,32 @@ def test_ghost_row_bookkeeping_self_check(hip_lib, tmp_path, nranks, k, nx, opts
     assert int(m.group(1)) > 20 and float(m.group(2)) < 1e-12, m.group(0)
 
 
+def test_strip_partition_at_the_benchmark_size(hip_lib, tmp_path):
+    """C3's mesh (k = 2, 1024^2) on 4 ranks: 256 rows per rank, 4-row halos, distributed finest multigrid level, every skipped
+    exchange verified (HDG_FLOW_CHECK); one step against the single-rank run."""
+    import re
+
+    from incompressibleeulerhdg_amd import _lib
+    from incompressibleeulerhdg_amd.mesh import UnitSquareMesh
+    from incompressibleeulerhdg_amd.model_problems import TaylorGreen
+    from incompressibleeulerhdg_amd.timesteppers import IncompressibleEulerHDGIMEXSSP2_332
+
+    k, nx, nranks = 2, 1024, 4
+    parts, logs = _run_ranks(nranks, k, nx, 1, tmp_path, env={"HDG_FLOW_CHECK": "1", "HDG_DEBUG": "1"}, want_logs=True)
+    Q, p, lam = _assemble(parts, k, nx)
+    dt = 0.25 / nx
+    ts = IncompressibleEulerHDGIMEXSSP2_332(UnitSquareMesh(nx, nx), k, dt, use_projection_method=True, n_richardson=2)
+    mp = TaylorGreen(ts._V_Q, ts._V_p)
+    Q1, p1 = ts.solve(*mp.initial_condition(), None, mp.f_rhs(), dt, fused=True)
+    lam1 = ts._engine.get_field(_lib.HDG_STATE_CURRENT, Q=False, p=False)[2]
+    rel = lambda a, b: np.max(np.abs(a - b)) / np.max(np.abs(b))
+    assert rel(Q, Q1.dat.data) < 2e-8 and rel(p, p1.dat.data) < 2e-8 and rel(lam, lam1) < 2e-8
+    s1, c1 = ts._engine.iteration_stats()
+    assert np.all(np.abs(parts[0]["its"][1:] - (s1 / np.maximum(c1, 1))[1:]) <= 1.0)
+    m = re.search(r"\[flow check\] (\d+) skipped exchanges verified, worst relative deviation ([0-9.eE+-]+)", logs[0])
+    assert m and int(m.group(1)) > 100 and float(m.group(2)) < 1e-12, logs[0][-1500:]
+
+
 def test_strip_partition_unsplit(hip_lib, tmp_path):
     from incompressibleeulerhdg_amd.mesh import UnitSquareMesh
     from incompressibleeulerhdg_amd.model_problems import TaylorGreen
