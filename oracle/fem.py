@@ -42,6 +42,8 @@ __all__ = [
     "PolySpace2D",
     "PolySpace1D",
     "Mesh",
+    "TriMesh",
+    "unit_disk_mesh",
 ]
 
 
@@ -293,3 +295,98 @@ class Mesh:
         if self.periodic:  # the point may be given in the other copy of the cell
             d = (d + 0.5 * self.L) % self.L - 0.5 * self.L
         return np.einsum("mrd,mqd->mqr", self.Jinv[cells], d)
+
+
+# --------------------------------------------------------------------------------------
+# general affine triangle meshes (the step the HIP path has NOT taken yet)
+# --------------------------------------------------------------------------------------
+
+
+class TriMesh:
+    """Conforming triangulation given by vertex coordinates [nv, 2] and cells [nc, 3] (vertex numbers).  Same attributes
+    as ``Mesh`` (per-cell affine map, edges with their two cells, outward normal of the '+' cell), so that
+    ``HDGDiscretisation(mesh=...)`` runs on it unchanged.  Edge numbering: order of first appearance while walking the
+    cells; edge direction: from the lower to the higher vertex number."""
+
+    periodic = False
+
+    def __init__(self, vertices, cells):
+        X = np.asarray(vertices, dtype=float)
+        C = np.asarray(cells, dtype=int)
+        self.vertices, self.cells = X, C
+        self.nx, self.L, self.h = 1, 1.0, None  # (only used to scale coordinate keys)
+        self.ncells = nc = len(C)
+        v = X[C]  # [nc, 3, 2]
+        self.cell_vertices = v
+        self.J = np.stack([v[:, 1] - v[:, 0], v[:, 2] - v[:, 0]], axis=-1)
+        self.detJ = np.abs(np.linalg.det(self.J))
+        self.Jinv = np.linalg.inv(self.J)
+        edges = {}
+        ea, eb, cp, cm = [], [], [], []
+        for c in range(nc):
+            for l in range(3):
+                i0, i1 = C[c, l], C[c, (l + 1) % 3]
+                key = (min(i0, i1), max(i0, i1))
+                if key in edges:
+                    e = edges[key]
+                    if cm[e] >= 0:
+                        raise ValueError("an edge with more than two cells")
+                    cm[e] = c
+                else:
+                    edges[key] = len(ea)
+                    ea.append(key[0]); eb.append(key[1]); cp.append(c); cm.append(-1)
+        self.nedges = len(ea)
+        self.edge_vertices = np.stack([np.array(ea), np.array(eb)], axis=1)
+        a, b = X[np.array(ea)], X[np.array(eb)]
+        cp, cm = np.array(cp), np.array(cm)
+        self.edge_a, self.edge_b = a, b
+        self.edge_plus, self.edge_minus = cp, cm
+        self.edge_len = np.linalg.norm(b - a, axis=1)
+        t = (b - a) / self.edge_len[:, None]
+        nrm = np.stack([t[:, 1], -t[:, 0]], axis=1)
+        flip = np.einsum("ed,ed->e", nrm, 0.5 * (a + b) - v[cp].mean(axis=1)) < 0
+        nrm[flip] *= -1
+        self.edge_normal_plus = nrm
+        self.interior = cm >= 0
+        self.volume = float(np.sum(self.detJ) / 2.0)
+
+    def ref_coords(self, cells, x):
+        d = x - self.cell_vertices[cells, 0][:, None, :]
+        return np.einsum("mrd,mqd->mqr", self.Jinv[cells], d)
+
+    def refined(self):
+        """Uniform refinement: every triangle into four through its edge midpoints."""
+        X = [tuple(p) for p in self.vertices]
+        mid = {}
+
+        def midpoint(i, j):
+            key = (min(i, j), max(i, j))
+            if key not in mid:
+                mid[key] = len(X)
+                X.append(tuple(0.5 * (self.vertices[i] + self.vertices[j])))
+            return mid[key]
+
+        cells = []
+        for (i, j, k) in self.cells:
+            a, b, c = midpoint(i, j), midpoint(j, k), midpoint(k, i)
+            cells += [(i, a, c), (a, j, b), (c, b, k), (a, b, c)]
+        return TriMesh(np.array(X), np.array(cells))
+
+
+def unit_disk_mesh(refinement_level=0):
+    """The unit disk as the reference builds it (``UnitDiskMesh(refinement_level)``, src/driver.py:184-185).
+
+    Restated from Firedrake's utility mesh of that name AS REMEMBERED (Firedrake is not available here: PARITY UNPINNED, and
+    the construction itself could not be compared with the library): the square [-1, 1]^2 cut into 8 triangles around the
+    origin, `refinement_level` uniform refinements, then every vertex x farther than 2^-(level+1) from the origin moved
+    radially to  x * max(|x_1|, |x_2|) / |x|  (squares concentric with the origin become circles)."""
+    X = np.array([[0, 0], [1, 0], [1, 1], [0, 1], [-1, 1], [-1, 0], [-1, -1], [0, -1], [1, -1]], dtype=float)
+    C = np.array([[0, 1, 2], [0, 2, 3], [0, 3, 4], [0, 4, 5], [0, 5, 6], [0, 6, 7], [0, 7, 8], [0, 8, 1]])
+    m = TriMesh(X, C)
+    for _ in range(refinement_level):
+        m = m.refined()
+    Y = m.vertices.copy()
+    r = np.linalg.norm(Y, axis=1)
+    move = r > 1.0 / (1 << (refinement_level + 1))
+    Y[move] *= (np.max(np.abs(Y[move]), axis=1) / r[move])[:, None]
+    return TriMesh(Y, m.cells)

@@ -45,8 +45,10 @@ class HDGDiscretisation:
     Reference: hdg_imex.py:65-70 (spaces), :313-365 (forms), common.py:36-57 (1/h_F).
     """
 
-    def __init__(self, nx, degree, variant="gll", tau=1.0, alpha_penalty=1.0, periodic=False, L=1.0):
-        self.mesh = mesh = Mesh(nx, periodic=periodic, L=L)
+    def __init__(self, nx, degree, variant="gll", tau=1.0, alpha_penalty=1.0, periodic=False, L=1.0, mesh=None):
+        # mesh: any object with the attributes of fem.Mesh (fem.TriMesh: general affine triangles, e.g. fem.unit_disk_mesh);
+        # nothing below depends on the mesh being structured
+        self.mesh = mesh = Mesh(nx, periodic=periodic, L=L) if mesh is None else mesh
         self.k = k = degree
         self.tau = float(tau)  # hdg_imex.py:58
         self.alpha = float(alpha_penalty)  # hdg_imex.py:56
@@ -567,6 +569,23 @@ class TaylorGreen:
             p = (1.0 - self.kappa * t) ** 2 * self.ps
         p = p - float(self.disc.int_p @ p)  # model_problems.py:104 (no division by the volume)
         return Q, p
+
+
+class KelvinHelmholtz:
+    """Kelvin-Helmholtz instability on the unit disk (model_problems.py:108-131): solid-body rotation (-y, x) inside the
+    radius 0.5 (a conditional, interpolated at the nodes), fluid at rest outside, p = 0, no forcing."""
+
+    def __init__(self, disc, r_max=0.5):
+        self.disc = disc
+        self.Qs = disc.interpolate_velocity(lambda x, y: (np.where(x ** 2 + y ** 2 < r_max ** 2, -y, 0.0),
+                                                          np.where(x ** 2 + y ** 2 < r_max ** 2, x, 0.0)))
+        self.ps = np.zeros(disc.NP)
+
+    def initial_condition(self):
+        return self.Qs.copy(), self.ps.copy()
+
+    def f_rhs(self, t):
+        return np.zeros_like(self.Qs)
 
 
 # ======================================================================================
