@@ -100,14 +100,18 @@ def roofline_block(eng, args, nx, k, world, ktimers=None, timed_where="the timed
     the other kernels a stand-alone launch loop on the engine's stream (hdg_time_kernel).
 
     An iteration of the tentative-velocity solve (55-60 % of the step) is two launches: the advection operator and
-    the hybrid preconditioner (BDM lift with the element block-Jacobi folded into the lifting tables).
-      k <= 2 (Chebyshev iteration):  k_adv_apply<K> in residual form t = b - (I - gamma F(Q*)) x  (reads x, Q*, b, writes t)
-                                     k_edge_lift<K,false,2> + fused Chebyshev step (reads t, x_n, x_{n-1}, writes x_{n+1})
-                                     4 vectors of 8 N_Q bytes each; bound: HBM.
-      k >= 3 (GMRES):                k_adv_mfma<K> (reads x, Q*, writes y) and k_edge_lift_mfma<K> (reads t, writes z) on the
-                                     matrix cores; bound: FP64 MFMA.  `achieved` counts the ALGORITHMIC flops (unpadded
-                                     contraction shapes), `mfma_util` the issued v_mfma_f64_16x16x4 (padding included).
-    Whichever of the two takes longer per launch is the dominant kernel."""
+    the hybrid preconditioner (BDM lift with the element block-Jacobi folded into the lifting tables).  The forms of a
+    kernel are separate instantiations with their own names (last template argument), so profiles tell them apart:
+      Chebyshev phase (default):  k_adv_apply<K, true> / k_adv_mfma<K, true>: residual form t = b - (I - gamma F(Q*)) x
+                                  (reads x, Q*, b, writes t: 4 vectors of 8 N_Q bytes, SURVEY.md section 8d);
+                                  k <= 2: k_edge_lift<K, false, 2, true> with the fused Chebyshev step (reads t, x_n, x_{n-1},
+                                  writes x_{n+1}: 4 vectors);  k >= 3: k_edge_lift_mfma<K> (reads t, writes z: 2 vectors) -- the
+                                  Chebyshev step is a separate vector kernel there (k_cheb_update, NOT inside the bracket);
+      GMRES phase:                k_adv_apply<K, false> / k_adv_mfma<K, false> (reads x, Q*, writes y: 3 vectors) and the plain
+                                  lift (2 vectors).
+    k <= 2: bound HBM.  k >= 3: bound FP64 MFMA; `achieved` counts the ALGORITHMIC flops (unpadded contraction shapes),
+    `mfma_util` the issued v_mfma_f64_16x16x4 (padding included).  Whichever of the two takes longer per launch is the
+    dominant kernel.  The brackets (hdg_set_kernel_timing) time the form the configured solver iterates with."""
     NQ = eng.n_cells * 2 * eng.n_u  # this rank's strip: kernel timings are per-rank launches
     NL = eng.n_edges * eng.n_l
     NP = eng.n_cells * eng.n_p
@@ -131,8 +135,9 @@ def roofline_block(eng, args, nx, k, world, ktimers=None, timed_where="the timed
             for cfg in tj["configs"].values():
                 if cfg["workload"] == {"nx": nx, "degree": k}:
                     kn = cfg["kernels"]
-                    for key, names in (("adv", (f"k_adv_apply<{k}>", f"k_adv_mfma<{k}>")),
-                                       ("lift", (f"k_edge_lift<{k}, false, 2>", f"k_edge_lift_mfma<{k}>"))):
+                    fm = "true" if cheb else "false"
+                    for key, names in (("adv", (f"k_adv_apply<{k}, {fm}>", f"k_adv_mfma<{k}, {fm}>")),
+                                       ("lift", (f"k_edge_lift<{k}, false, 2, {fm}>", f"k_edge_lift_mfma<{k}>"))):
                         for nm in names:
                             if nm in kn and (k <= 2) == ("mfma" not in nm):
                                 pmc[key] = kn[nm]["hbm_bytes"]
@@ -148,8 +153,8 @@ def roofline_block(eng, args, nx, k, world, ktimers=None, timed_where="the timed
         (ms_lift, n_lift), (ms_adv, n_adv) = in_place("kernel_lift", ms_lift_alone), in_place("kernel_advection", ms_adv_alone)
         nv_lift = ((4 if hybrid else 6) if cheb else 2)
         nv_adv = 4 if cheb else 3
-        lift_name = (f"k_edge_lift<{k},false,{2 if hybrid else 1}>" + (" + Chebyshev step" if cheb else ""))
-        adv_name = f"k_adv_apply<{k}>" + (" (residual form b - (I - gamma F) x)" if cheb else "")
+        lift_name = (f"k_edge_lift<{k}, false, {2 if hybrid else 1}, {'true' if cheb else 'false'}>" + (" (lift + fused Chebyshev step)" if cheb else ""))
+        adv_name = f"k_adv_apply<{k}, {'true' if cheb else 'false'}>" + (" (residual form b - (I - gamma F) x)" if cheb else "")
         cand = {"lift": (lift_name, 8.0 * nv_lift * NQ, ms_lift), "adv": (adv_name, 8.0 * nv_adv * NQ, ms_adv)}
         dom = "adv" if ms_adv >= ms_lift else "lift"
         oth = "lift" if dom == "adv" else "adv"
@@ -175,7 +180,7 @@ def roofline_block(eng, args, nx, k, world, ktimers=None, timed_where="the timed
     ne = k + 2
     lift_issued = (5 * ks + 5 * mt) * 2048.0 * tiles
     lift_alg = eng.n_cells * (2.0 * 3 * ne * n2 * 2 + 2.0 * n2 * 3 * ne)  # own + neighbour moments, lifting
-    ms_adv_alone = eng.time_kernel(0, 20)
+    ms_adv_alone = eng.time_kernel(7 if cheb else 0, 20)
     ms_lift_alone = eng.time_kernel(9, 20)
     in_place = lambda lab, alone: (ktimers[lab][1] / ktimers[lab][0] * 1e3, ktimers[lab][0]) if ktimers and ktimers.get(lab, (0, 0))[0] else (alone, 0)
     (ms_lift, n_lift), (ms_adv, n_adv) = in_place("kernel_lift", ms_lift_alone), in_place("kernel_advection", ms_adv_alone)
@@ -183,13 +188,15 @@ def roofline_block(eng, args, nx, k, world, ktimers=None, timed_where="the timed
     others[f"k_edge_lift_mfma<{k}>"] = dict(ms=ms_lift, TFLOPs=tf(lift_alg, ms_lift), mfma_util=tf(lift_issued, ms_lift) / FP64_MATRIX_PEAK_TF,
                                              GBs=gbs(8.0 * 2 * NQ, ms_lift), algorithmic_bytes=8.0 * 2 * NQ, traffic=pmc.get("lift"),
                                              mfma_busy_pmc=pmc_mfma.get("lift"), launches_timed=n_lift, ms_stand_alone=ms_lift_alone)
-    return dict(bound="mfma", kernel=f"k_adv_mfma<{k}>", achieved=tf(adv_alg, ms_adv), peak=FP64_MATRIX_PEAK_TF, unit="TFLOP/s",
+    nv_adv = 4 if cheb else 3  # residual form reads b as well
+    return dict(bound="mfma", kernel=f"k_adv_mfma<{k}, {'true' if cheb else 'false'}>" + (" (residual form)" if cheb else ""),
+                achieved=tf(adv_alg, ms_adv), peak=FP64_MATRIX_PEAK_TF, unit="TFLOP/s",
                 frac=tf(adv_alg, ms_adv) / FP64_MATRIX_PEAK_TF, mfma_util=tf(adv_issued, ms_adv) / FP64_MATRIX_PEAK_TF,
                 mfma_busy_pmc=pmc_mfma.get("adv"),  # SQ_VALU_MFMA_BUSY_CYCLES / (kernel cycles x 1024 SIMDs), profiles/pmc_traffic.json
                 algorithmic_flops=adv_alg, issued_mfma_flops=adv_issued, ms_per_launch=ms_adv, traffic=pmc.get("adv"),
                 timing=("in place: HIP-event pair around each launch of " + timed_where) if n_adv else "stand-alone launch loop",
                 launches_timed=n_adv, ms_stand_alone=ms_adv_alone,
-                hbm_GBs=gbs(8.0 * 3 * NQ, ms_adv), algorithmic_bytes=8.0 * 3 * NQ, stream_triad_GBs=triad, other_kernels=others)
+                hbm_GBs=gbs(8.0 * nv_adv * NQ, ms_adv), algorithmic_bytes=8.0 * nv_adv * NQ, stream_triad_GBs=triad, other_kernels=others)
 
 
 def cpu_baseline(degree, nx_sample=None):
@@ -224,10 +231,62 @@ def cpu_baseline(degree, nx_sample=None):
     its = [float(a / max(b, 1)) for a, b in zip(sums, cnt)]
     # the reference's PerformanceLog labels (logging.py:34-60), as for the GPU run's `timers`
     tm = {lab: {"ncall": n, "total_ms": 1e3 * sec, "avg_ms": 1e3 * sec / max(n, 1)} for lab, (sec, n) in t.timers().items()}
-    return dict(value=t.n_total * nsteps / el / 1e6, unit="million DOF-updates/s", cores=t.threads, kind="port", timers=tm,
+    return dict(value=t.n_total * nsteps / el / 1e6, unit="million DOF-updates/s", cores=t.threads, kind="port", timers=tm, nx_sample=nx,
                 sample=f"C++/OpenMP twin (oracle/cpu_twin), HDG-IMEX SSP2(3,3,2) R=2 upwind k={degree} nx={nx} "
                        f"({t.n_total} unknowns), {t.threads} threads, 1 warm-up + {nsteps} timed steps in {el:.1f} s; "
                        f"Krylov iterations tentative/pressure {its[0]:.1f}/{its[1]:.1f} (GMRES(8) / PCG)")
+
+
+def gpu_at_size(nx, k, args, kappa):
+    """The GPU path on the CPU sample's mesh (same scheme, 1 warm-up + 3 timed steps), so that GPU and CPU numbers exist at
+    ONE size as well as the GPU number at the headline size."""
+    from incompressibleeulerhdg_amd.mesh import UnitSquareMesh
+    from incompressibleeulerhdg_amd.model_problems import TaylorGreen
+    from incompressibleeulerhdg_amd.timesteppers import IncompressibleEulerHDGIMEXSSP2_332
+
+    dt = 0.25 / nx
+    ts = IncompressibleEulerHDGIMEXSSP2_332(UnitSquareMesh(nx, nx), k, dt, use_projection_method=True, n_richardson=2,
+                                            tent_precond=args.tent_precond, trace_precond=args.trace_precond,
+                                            gmres_restart=args.gmres_restart,
+                                            **({} if args.tent_solver is None else {"tent_solver": args.tent_solver}))
+    eng = ts._engine
+    mp = TaylorGreen(ts._V_Q, ts._V_p, "exponential", kappa)
+    eng.set_state(ts._V_Q.interpolate(mp.Q_stationary), ts._V_p.interpolate(mp.p_stationary))
+    eng.reconstruct_trace()
+    eng.set_forcing_profile(mp.f_rhs().profile)
+    eng.run_separable(ssp2_scales(1, dt, kappa))
+    nsteps = 3
+    t0 = time.perf_counter()
+    eng.run_separable(ssp2_scales(nsteps, dt, kappa, t0=dt))  # synchronous on return
+    el = time.perf_counter() - t0
+    out = dict(value=eng.n_total * nsteps / el / 1e6, unit="million DOF-updates/s", nx=nx, ms_per_step=el / nsteps * 1e3)
+    eng.close()
+    return out
+
+
+def reassembly_split(eng, k, nx, cb, gpu_s_per_step):
+    """BASELINE.md section 4 / SURVEY.md C-11: the reference re-assembles and re-condenses the time-independent mixed-Poisson
+    operator on every one of its (s-1) R + 2 solves per step (LinearVariationalProblem without constant_jacobian,
+    hdg_imex.py:180-182,190-192,209-213; Slate: per cell LU of the (n_Q+n_p)^2 block, A^-1 G and the Schur complement);
+    the engine and the CPU twin build the two shared shape blocks once.  A ONE-LINE ESTIMATE of what that saving is worth,
+    so that it is not mistaken for kernel efficiency: flops of the per-cell elimination x cells x solves per step, priced
+    at the FP64 rate each side sustains in its densest kernel (GPU: FP64 vector/matrix peak 78.6 TF; CPU: the twin's
+    measured rate is unknown, so 16 cores x 16 flop/cycle x 2.5 GHz = 0.64 TF as an optimistic bound)."""
+    nxx = 2 * eng.n_u + eng.n_p
+    nt = 3 * eng.n_l
+    flops_cell = 2.0 / 3.0 * nxx**3 + 2.0 * nxx * nxx * nt + 2.0 * nt * nxx * nt
+    solves = (3 - 1) * 2 + 2  # SSP2(3,3,2), R = 2
+    per_step = lambda ncell: flops_cell * ncell * solves
+    gpu_extra = per_step(2.0 * nx * nx) / (FP64_MATRIX_PEAK_TF * 1e12)
+    cpu_nx = cb["gpu_same_size"]["nx"]
+    cpu_s_per_step = 1e-3 * cb["timers"]["timestep"]["avg_ms"] if "timestep" in cb.get("timers", {}) else None
+    cpu_extra = per_step(2.0 * cpu_nx * cpu_nx) / 0.64e12
+    return dict(solves_per_step=solves, flops_per_cell_elimination=flops_cell,
+                gpu_extra_ms_per_step_if_reassembled=gpu_extra * 1e3, gpu_share_of_step=gpu_extra / gpu_s_per_step,
+                cpu_extra_ms_per_step_if_reassembled=cpu_extra * 1e3,
+                cpu_share_of_step=(cpu_extra / cpu_s_per_step) if cpu_s_per_step else None,
+                note="lower bounds at peak FP64 rates: not re-assembling is worth at least these shares on either side; "
+                     "both sides of the reported GPU/CPU ratio skip it, so the ratio is kernel + solver efficiency only")
 
 
 def main():
@@ -345,14 +404,14 @@ def main():
         eng.run_separable(ssp2_scales(args.warmup, dt, kappa))
     eng.iteration_stats(reset=True)
     eng.timers(reset=True)
-    # every launch of the two kernels of a tentative-velocity iteration is bracketed by its own HIP-event pair on the
-    # engine's stream DURING the timed steps (hdg_set_kernel_timing: in place, with the operands and cache state of the
-    # solve); the roofline block divides by these durations.  Cost: two event records per launch, < 0.5 % of a step
-    # (BENCH_KERNEL_TIMING=extra moves the brackets to one extra step after the timed region instead).
-    # Small problems (kernels of 5-20 us: C2) would be perturbed by the brackets themselves (+15 % per step measured at
-    # k = 1, 256^2): there, and on request, the brackets go to one extra step after the timed region.
-    ktiming_extra = os.environ.get("BENCH_KERNEL_TIMING", "timed" if nx >= 512 else "extra") == "extra"
+    # Every launch of the two kernels of a tentative-velocity iteration can be bracketed by its own HIP-event pair on the
+    # engine's stream (hdg_set_kernel_timing: in place, with the operands and cache state of the solve); the roofline block
+    # divides by these durations.  The brackets cost two event records per launch (about 1 % of a C3 step, 15 % at C2), so
+    # by default they bracket ONE EXTRA step after the timed region: the headline does not pay for its own instrumentation.
+    # BENCH_KERNEL_TIMING=timed puts them into the timed steps instead.
+    ktiming_extra = os.environ.get("BENCH_KERNEL_TIMING", "extra") == "extra"
     eng.set_kernel_timing(not ktiming_extra)
+    eng.launch_stats(reset=True)
     sync_barrier()
     t0 = time.perf_counter()
     eng.run_separable(ssp2_scales(args.steps, dt, kappa, t0=args.warmup * dt))  # synchronous on return
@@ -361,6 +420,7 @@ def main():
     if dist is not None:
         elapsed = reduce_scalar(elapsed, dist.ReduceOp.MAX)
     sums, cnt = eng.iteration_stats()
+    launches = eng.launch_stats(reset=True)  # launch census of exactly the timed steps (this rank)
     timers_raw = eng.timers(reset=ktiming_extra, kernels=True)
     if ktiming_extra:
         eng.set_kernel_timing(True)
@@ -380,6 +440,17 @@ def main():
         timers = {lab: dict(ncall=n, total_ms=tot * 1e3, avg_ms=(tot / n * 1e3 if n else 0.0))
                   for lab, (n, tot, _) in timers_raw.items() if n}
         roof = roofline_block(eng, args, nx, k, world, ktimers, "one extra step after the timed region" if ktiming_extra else "the timed steps")
+        # Whole-step roofline (SURVEY.md section 8d / BASELINE.md section 2): sum_k calls_k * algorithmic_bytes_k / elapsed / peak,
+        # from the engine's own launch census of the timed steps (every logical vector read or written once per launch,
+        # 8 B per owned entry, shared operator tables free; this rank's strip x number of ranks).
+        tot_bytes = sum(b for _, b in launches.values()) * world
+        tot_calls = sum(c for c, _ in launches.values())
+        roof["whole_step"] = dict(
+            achieved=tot_bytes / elapsed / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=tot_bytes / elapsed / 1e9 / HBM_PEAK_GBS,
+            algorithmic_GB_per_step=tot_bytes / args.steps / 1e9, launches_per_step=tot_calls / args.steps,
+            avg_us_per_launch=elapsed / max(tot_calls, 1) * 1e6,
+            calls_k={lab: dict(calls_per_step=c / args.steps, GB_per_step=b * world / args.steps / 1e9)
+                     for lab, (c, b) in launches.items() if c})
         line = {
             "metric": "million DOF-updates/sec (HDG-IMEX k=2, 1024^2 tri mesh)" if (nx, k) == (1024, 2)
             else f"million DOF-updates/sec (HDG-IMEX k={k}, {nx}^2 tri mesh)",
@@ -396,7 +467,14 @@ def main():
             "timers": timers,
         }
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(k)
+            cb = cpu_baseline(k)
+            # the GPU number at the CPU sample's size ("report DOF-updates/s at that size next to the
+            # GPU number at the same size and at C3")
+            nxs = cb.pop("nx_sample")
+            cb["gpu_same_size"] = gpu_at_size(nxs, k, args, kappa)
+            cb["gpu_over_cpu_same_size"] = cb["gpu_same_size"]["value"] / cb["value"]
+            cb["reassembly_split"] = reassembly_split(eng, k, nx, cb, elapsed / args.steps)
+            line["cpu_baseline"] = cb
         print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()

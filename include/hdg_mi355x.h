@@ -178,6 +178,16 @@ int hdg_get_timers(hdg_handle* h, double* total_ms, double* sumsq_ms, long* ncal
  * Chebyshev step / plain) -- bracketed by its own event pair IN PLACE, i.e. with the operands and cache state of the
  * solve.  Recorded only while switched on (two event records per launch: about 1 % of a C3 step). */
 int hdg_set_kernel_timing(hdg_handle* h, int on);
+/* Launch census since the last reset (no reference counterpart; SURVEY.md section 8(d): "roofline.achieved = sum_k calls_k *
+ * bytes_k / elapsed / BW_peak with calls_k printed alongside"): per kernel class the number of launches and the ALGORITHMIC
+ * bytes they moved -- every logical vector read or written once per launch, 8 B per owned entry, shared operator tables
+ * free.  Classes: 0 advection_apply (K3), 1 edge_lift (K1, K4: BDM projection / two-level
+ * preconditioner, incl. the fused Chebyshev step), 2 stage_rhs (K2: pressure-gradient combination, reconstruction rhs),
+ * 3 weak_divergence, 4 condense (K5), 5 trace_apply (K6), 6 trace_smooth (K7: smoother steps on the trace space),
+ * 7 backsub (K8), 8 vertex_multigrid (K7: P1 V-cycle and transfers), 9 vector_update (K9), 10 dot (K9),
+ * 11 copy_fill, 12 other (scalar kernels, trace reconstruction, constraint rows). */
+#define HDG_N_LAUNCH_CLASSES 13
+int hdg_get_launch_stats(hdg_handle* h, long* calls, double* bytes, int reset);
 
 /* ---- passive tracer.  Explicit DG transport of a scalar in DG_k by the L2 projection of
  * the stage velocity onto [CG_{k+1}]^2 (common.py:110-129): q_i = q_0 + dt sum_{j<i} a_expl[i,j] M^-1 T(q_j, P(Q_i))
@@ -223,7 +233,9 @@ int hdg_apply_weak_divergence(hdg_handle* h, const double* Q, int broken, double
  *         4 BDM lift + block-Jacobi + Chebyshev step (fused; additive preconditioner), 5 transposed BDM lift,
  *         6 hybrid preconditioner (BDM lift + block-Jacobi of the remainder) + Chebyshev step (fused),
  *         7 advection apply in residual form  b - (I - gamma F) x,
- *         8 stream triad y = a x + b y on two velocity-sized vectors (the box's achievable HBM rate) */
+ *         8 stream triad y = a x + b y on two velocity-sized vectors (the box's achievable HBM rate),
+ *         9 hybrid preconditioner without the Chebyshev step (k >= 3: matrix-core lift), 10 condensation (pressure-row
+ *         form), 11 pressure-gradient combination, 12 weak divergence, 13 pressure-reconstruction right-hand side */
 int hdg_time_kernel(hdg_handle* h, int kernel, int reps, double* ms_per_launch);
 
 #ifdef __cplusplus

@@ -73,7 +73,7 @@ class hdg_config(C.Structure):
 
 def build_library(force=False, verbose=False):
     """Compile the HIP engine for gfx950 into the package directory (in-tree, travels with gpurun)."""
-    srcs = [SRC, HEADER] + [os.path.join(_HERE, "csrc", f) for f in ("hdg_kernels.hpp", "hdg_tables.hpp", "hdg_comm.hpp")]
+    srcs = [SRC, HEADER] + [os.path.join(_HERE, "csrc", f) for f in ("hdg_kernels.hpp", "hdg_schur_mfma.hpp", "hdg_tables.hpp", "hdg_comm.hpp", "hdg_cg.hpp")]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -122,6 +122,7 @@ SIGNATURES = {
     "hdg_rccl_selftest": [C.c_int, C.c_int, _dp],
     "hdg_get_timers": [_h, _dp, _dp, _lp, C.c_int],
     "hdg_set_kernel_timing": [_h, C.c_int],
+    "hdg_get_launch_stats": [_h, _lp, _dp, C.c_int],
     "hdg_set_tracer": [_h, _dp],
     "hdg_get_tracer": [_h, _dp],
     "hdg_tracer_begin_step": [_h],
@@ -418,6 +419,17 @@ class Engine:
         self._ck(self.lib.hdg_get_timers(self.h, _ptr(tot), _ptr(sq), cnt.ctypes.data_as(_lp), 1 if reset else 0))
         labels = self.TIMER_LABELS + (self.KERNEL_TIMER_LABELS if kernels else ())
         return {lab: (int(c), t * 1e-3, q * 1e-6) for lab, c, t, q in zip(labels, cnt, tot, sq)}
+
+    LAUNCH_CLASSES = ("advection_apply", "edge_lift", "stage_rhs", "weak_divergence", "condense", "trace_apply", "trace_smooth",
+                      "backsub", "vertex_multigrid", "vector_update", "dot", "copy_fill", "other")
+
+    def launch_stats(self, reset=False):
+        """Launch census since the last reset: {class: (launches, algorithmic bytes)} (hdg_get_launch_stats)."""
+        n = len(self.LAUNCH_CLASSES)
+        calls = np.zeros(n, dtype=np.int64)
+        nbytes = np.zeros(n)
+        self._ck(self.lib.hdg_get_launch_stats(self.h, calls.ctypes.data_as(_lp), _ptr(nbytes), 1 if reset else 0))
+        return {lab: (int(c), float(b)) for lab, c, b in zip(self.LAUNCH_CLASSES, calls, nbytes)}
 
     def set_kernel_timing(self, on):
         self._ck(self.lib.hdg_set_kernel_timing(self.h, 1 if on else 0))

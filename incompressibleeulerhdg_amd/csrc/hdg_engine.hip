@@ -29,6 +29,7 @@
 #include "../../include/hdg_mi355x.h"
 #include "hdg_comm.hpp"
 #include "hdg_kernels.hpp"
+#include "hdg_schur_mfma.hpp"
 #include "hdg_cg.hpp"
 #include "hdg_tables.hpp"
 
@@ -109,7 +110,12 @@ struct Engine {
   double tr_one_nn = -1.0;
   // operator sets of the hybridised mixed Poisson problem, one per stabilisation parameter tau':
   // set 0 (tau) serves the projection method; the unsplit solves use tau/gamma (see mono_precond)
-  struct PSet { DevTables dt; double lmin, lmax, tau; };
+  struct PSet {
+    DevTables dt; double lmin, lmax, tau;
+    // the same local maps in A-operand lane order for the matrix-core kernels (k >= 3; built on first use)
+    const double* bsm[2] = {nullptr, nullptr};  // back-substitution: [Ainv | -W], rows (u in memory order | phi)
+    const double* cdm = nullptr;                // condensation: the four cell blocks of Y around a corner
+  };
   std::vector<PSet> psets;
   int cur_pset = 0;
   const DevTables& pdt() const { return psets[cur_pset].dt; }
@@ -165,6 +171,25 @@ struct Engine {
     }
     ~KTimed() { if (on) { (void)hipEventRecord(sec.e1, E.stream); E.tm_open.push_back(sec); } }
   };
+  // inside a long fused run (hdg_run_separable): harvest the sections whose closing event has completed, so that the list
+  // of live events stays bounded (two events per section, and with kernel timing two per bracketed launch)
+  void harvest_completed() {
+    size_t keep = 0;
+    for (size_t q = 0; q < tm_open.size(); q++) {
+      const Section sc = tm_open[q];
+      float ms = 0.0f;
+      if (hipEventQuery(sc.e1) == hipSuccess && hipEventElapsedTime(&ms, sc.e0, sc.e1) == hipSuccess) {
+        tm_total[sc.label] += ms;
+        tm_sumsq[sc.label] += (double)ms * ms;
+        tm_calls[sc.label]++;
+        tm_pool.push_back(sc.e0);
+        tm_pool.push_back(sc.e1);
+      } else {
+        tm_open[keep++] = sc;
+      }
+    }
+    tm_open.resize(keep);
+  }
   void harvest_timers() {  // the stream must have been synchronised
     for (const Section& sc : tm_open) {
       float ms = 0.0f;
@@ -310,8 +335,8 @@ struct Engine {
   }
   ~Engine() {
     if (debug_on() && comm && comm->rank == 0)
-      fprintf(stderr, "[comm] halo exchanges: velocity %ld, pressure %ld, trace %ld; all-reduces %ld; all-gathers %ld\n",
-              n_halo[0], n_halo[1], n_halo[2], n_reduce, n_gather);
+      fprintf(stderr, "[comm] halo exchanges: velocity %ld, pressure %ld, trace %ld, vertex rows %ld; all-reduces %ld; all-gathers %ld\n",
+              n_halo[0], n_halo[1], n_halo[2], n_halo_mg, n_reduce, n_gather);
     if (flow_check && comm && comm->rank == 0)
       fprintf(stderr, "[flow check] %ld skipped exchanges verified, worst relative deviation %.3e\n", fc_count, fc_worst);
     release();
@@ -410,6 +435,28 @@ struct Engine {
   // consistent copies consistent.)
   bool halo_on = true;  // switched off while timing bare kernel launches (hdg_time_kernel is not collective)
   long n_halo[3] = {0, 0, 0}, n_reduce = 0, n_gather = 0;  // communication census (HDG_DEBUG, printed at destruction)
+  long n_halo_mg = 0;  // vertex-row exchanges of the distributed V-cycle level (their own counter: not pressure halos)
+  // ------------------------------------------------------------------ launch census (hdg_get_launch_stats)
+  // Launches and ALGORITHMIC bytes per kernel class: every logical vector read or written once per launch, 8 B per OWNED
+  // entry (no ghost / padding rows), shared operator tables free -- SURVEY.md section 8(d).  bench.py's whole-step roofline is
+  // sum_k bytes_k / elapsed / peak with calls_k printed alongside.  Classes follow the kernel list K1..K9 of SURVEY 7.3.
+  enum { LC_ADV = 0, LC_LIFT, LC_RHS, LC_WDIV, LC_CONDENSE, LC_TRACE_APPLY, LC_TRACE_SMOOTH, LC_BACKSUB, LC_MG, LC_VEC, LC_DOT,
+         LC_COPY, LC_OTHER, LC_N };
+  long lc_calls[HDG_N_LAUNCH_CLASSES] = {0};
+  double lc_bytes[HDG_N_LAUNCH_CLASSES] = {0};
+  static_assert(LC_N == HDG_N_LAUNCH_CLASSES, "launch classes out of step with the header");
+  void tally(int c, double bytes) { lc_calls[c]++; lc_bytes[c] += bytes; }
+  double bQ() const { return 8.0 * (double)NQb; }
+  double bP() const { return 8.0 * (double)NPb; }
+  double bL() const { return 8.0 * (double)NLb; }
+  // bytes of one pass over a whole-array vector of allocated length n (owned entries only)
+  double bvec(long n) const {
+    if (n == NQ) return bQ();
+    if (n == NPv) return bP();
+    if (n == NLv) return bL();
+    if (n == g.Nc) return 8.0 * 2.0 * g.nx * g.ny;
+    return 8.0 * (double)n;
+  }
   void halo_rows(double* v, long plane_stride, int row_len, int nplanes, int kind, int depth = 1, int gh = GH) {
     if (periodic && halo_on) {  // ghost rows = the owned rows of the opposite side
       k_wrap_rows<<<std::min(vec_blocks((long)nplanes * row_len * gh), 512), 256, 0, stream>>>(v, plane_stride, row_len, nplanes, g.ny, gh);
@@ -553,7 +600,7 @@ struct Engine {
   // Out[e]: 2nu x ne row-major lifting tables of shape s (Lift_e for the projection, (I - Dinv) Lift_e for the
   // hybrid preconditioner).
   std::vector<double> pack_lift_mfma(int s_, const dvec* Out) const {
-    const int n2 = 2 * tab->nu, ne = tab->ne, KS = (n2 + 3) / 4, MT = (n2 + 15) / 16, KD = 5;
+    const int n2 = 2 * tab->nu, ne = tab->ne, KS = 2 * ((tab->nu + 3) / 4), MT = (tab->nu + 7) / 8, KD = 5;
     auto tile = [&](std::vector<double>& dstv, int rows, int cols, const std::vector<double>& M, int mt, int ks) {
       for (int l = 0; l < 64; l++) {
         const int r = 16 * mt + l % 16, c = 4 * ks + l / 16;
@@ -561,30 +608,30 @@ struct Engine {
       }
     };
     std::vector<double> packed;
-    // The kernel walks the velocity dofs in memory order kappa = 2m + d (component-pair layout); the tables
-    // are indexed n = d*nu + m: kap[n] is the position of table column / row n in the packed matrices.
-    const int nu_ = tab->nu;
-    std::vector<int> kap(n2);
-    for (int n = 0; n < n2; n++) kap[n] = 2 * (n % nu_) + n / nu_;
+    // The kernel assigns the velocity dofs to K slots / result rows so that a lane moves whole 16-byte component pairs
+    // (k_edge_lift_mfma); the tables are indexed n = d*nu + m: kcol[n] / krow[n] are the positions of table column / row n.
+    std::vector<int> kcol(n2), krow(n2);
+    for (int n = 0; n < n2; n++) { kcol[n] = scol(n); krow[n] = srow(n); }
     // W: rows (e, a) packed as tile 0 = edges 0, 1, tile 1 = edge 2;  W = -N[s][e]
-    std::vector<double> W((size_t)32 * n2, 0.0);
+    const int nc = 4 * KS;  // padded column count of the coefficient side
+    std::vector<double> W((size_t)32 * nc, 0.0);
     for (int e = 0; e < 3; e++)
       for (int a = 0; a < ne; a++)
-        for (int n = 0; n < n2; n++) W[(size_t)((e < 2 ? e * ne + a : 16 + a)) * n2 + kap[n]] = -tab->N[s_][e][a * n2 + n];
-    for (int mt = 0; mt < 2; mt++) for (int ks = 0; ks < KS; ks++) tile(packed, 32, n2, W, mt, ks);
+        for (int n = 0; n < n2; n++) W[(size_t)((e < 2 ? e * ne + a : 16 + a)) * nc + kcol[n]] = -tab->N[s_][e][a * n2 + n];
+    for (int mt = 0; mt < 2; mt++) for (int ks = 0; ks < KS; ks++) tile(packed, 32, nc, W, mt, ks);
     // N'_e = N[1 - s][e], rows at their position inside the tile
     for (int e = 0; e < 3; e++) {
-      std::vector<double> Np((size_t)16 * n2, 0.0);
+      std::vector<double> Np((size_t)16 * nc, 0.0);
       for (int a = 0; a < ne; a++)
-        for (int n = 0; n < n2; n++) Np[(size_t)((e == 1 ? ne : 0) + a) * n2 + kap[n]] = tab->N[1 - s_][e][a * n2 + n];
-      for (int ks = 0; ks < KS; ks++) tile(packed, 16, n2, Np, 0, ks);
+        for (int n = 0; n < n2; n++) Np[(size_t)((e == 1 ? ne : 0) + a) * nc + kcol[n]] = tab->N[1 - s_][e][a * n2 + n];
+      for (int ks = 0; ks < KS; ks++) tile(packed, 16, nc, Np, 0, ks);
     }
     // G: columns = packed moments, K index q: q < 12 -> tile 0 row q, q >= 12 -> tile 1 row q - 12
     std::vector<double> Gm((size_t)(16 * MT) * 20, 0.0);
     for (int e = 0; e < 3; e++)
       for (int a = 0; a < ne; a++) {
         const int q = e < 2 ? e * ne + a : 12 + a;
-        for (int n = 0; n < n2; n++) Gm[(size_t)kap[n] * 20 + q] = Out[e][(size_t)n * ne + a];
+        for (int n = 0; n < n2; n++) Gm[(size_t)krow[n] * 20 + q] = Out[e][(size_t)n * ne + a];
       }
     for (int mt = 0; mt < MT; mt++) for (int kd = 0; kd < KD; kd++) tile(packed, 16 * MT, 20, Gm, mt, kd);
     return packed;
@@ -635,6 +682,123 @@ struct Engine {
     for (int mu = 0; mu < MTU; mu++) for (int kd = 0; kd < 6; kd++) tile(nu, 24, ET, mu, kd);
     return packed;
   }
+  // ---- matrix-core Schur kernels (hdg_schur_mfma.hpp, k >= 3): local maps in A-operand lane order.
+  // tiles of a dense rows x cols matrix, order [mt][ks]; tile entry l = M[16 mt + l % 16][4 ks + l / 16] (zero outside)
+  static void pack_tiles(std::vector<double>& dst, const std::vector<double>& M, int rows, int cols, int MT, int KS) {
+    for (int mt = 0; mt < MT; mt++)
+      for (int ks = 0; ks < KS; ks++)
+        for (int l = 0; l < 64; l++) {
+          const int r = 16 * mt + l % 16, c = 4 * ks + l / 16;
+          dst.push_back((r < rows && c < cols) ? M[(size_t)r * cols + c] : 0.0);
+        }
+  }
+  int kap(int n) const { return 2 * (n % NU) + n / NU; }  // memory position (component-pair layout) of table dof n = d*NU + m
+  // K slot / result row of table dof n = d*NU + m in the matrix-core Schur kernels (16-byte accesses, hdg_schur_mfma.hpp)
+  int scol(int n) const { const int m = n % NU, d = n / NU; return 8 * (m / 4) + 4 * d + m % 4; }
+  int srow(int n) const { const int m = n % NU, d = n / NU; return 16 * (m / 8) + m % 4 + 4 * (2 * ((m % 8) / 4) + d); }
+  int sKSU() const { return 2 * ((NU + 3) / 4); }
+  int sMTU() const { return (NU + 7) / 8; }
+  // back-substitution  (u, phi) = Ainv (r_w, r_p) - W lambda:  rows [u in memory order, padded to 16 MTU | phi],
+  // columns [r_w in memory order, padded to 4 KSU | r_p padded to 4 KSP | lambda padded to 4 KST]
+  std::vector<double> pack_backsub_mfma(const dvec& Ai, const dvec& W_) const {
+    const int N2 = 2 * NU, NT = 3 * NL, KSU = sKSU(), KSP = (NP + 3) / 4, KST = (NT + 3) / 4, MTU = sMTU();
+    const int rows = 16 * (MTU + 1), cols = 4 * (KSU + KSP + KST);
+    std::vector<double> M((size_t)rows * cols, 0.0);
+    for (int n = 0; n < NX; n++) {
+      const int r = n < N2 ? srow(n) : 16 * MTU + (n - N2);
+      for (int c = 0; c < N2; c++) M[(size_t)r * cols + scol(c)] = Ai[(size_t)n * NX + c];
+      for (int m = 0; m < NP; m++) M[(size_t)r * cols + 4 * KSU + m] = Ai[(size_t)n * NX + N2 + m];
+      for (int q = 0; q < NT; q++) M[(size_t)r * cols + 4 * (KSU + KSP) + q] = -W_[(size_t)n * NT + q];
+    }
+    std::vector<double> out;
+    pack_tiles(out, M, rows, cols, MTU + 1, KSU + KSP + KST);
+    return out;
+  }
+  // condensation: one M-tile with rows (H, D, V) x NL; block 0 = Y_L (local edges 0, 1, 2 -> H, D, V), blocks 1, 2, 3 = the
+  // rows of Y_U that belong to D (local edge 1), H (0), V (2); columns [r_w in memory order | r_p] per block
+  std::vector<double> pack_condense_mfma(const dvec& Y0, const dvec& Y1) const {
+    const int N2 = 2 * NU, NT = 3 * NL, KSU = sKSU(), KSP = (NP + 3) / 4, KSA = KSU + KSP, cols = 4 * KSA;
+    std::vector<double> out;
+    for (int q = 0; q < 4; q++) {
+      std::vector<double> M((size_t)16 * cols, 0.0);
+      const dvec& Y = q == 0 ? Y0 : Y1;
+      for (int e = 0; e < 3; e++) {
+        if (q == 1 && e != 1) continue;
+        if (q == 2 && e != 0) continue;
+        if (q == 3 && e != 2) continue;
+        for (int a = 0; a < NL; a++) {
+          const int r = e * NL + a;  // local-edge order (0, 1, 2) = (H, D, V): the row order of the result tile
+          for (int c = 0; c < N2; c++) M[(size_t)r * cols + scol(c)] = Y[(size_t)r * NX + c];
+          for (int m = 0; m < NP; m++) M[(size_t)r * cols + 4 * KSU + m] = Y[(size_t)r * NX + N2 + m];
+        }
+      }
+      pack_tiles(out, M, 16, cols, 1, KSA);
+    }
+    (void)NT;
+    return out;
+  }
+  // pressure gradient: rows = velocity dofs in memory order, columns [p | lambda (e, m)]:  B^T p - sum_e sigma_e N_e^T lambda_e
+  std::vector<double> pack_pgrad_mfma(int sh) const {
+    const int N2 = 2 * NU, NT = 3 * NL, KSP = (NP + 3) / 4, KST = (NT + 3) / 4, MTU = sMTU(), cols = 4 * (KSP + KST);
+    std::vector<double> M((size_t)16 * MTU * cols, 0.0);
+    for (int n = 0; n < N2; n++) {
+      for (int m = 0; m < NP; m++) M[(size_t)srow(n) * cols + m] = tab->B[sh][(size_t)m * N2 + n];
+      for (int e = 0; e < 3; e++)
+        for (int m = 0; m < NL; m++) M[(size_t)srow(n) * cols + 4 * KSP + e * NL + m] = -tab->sig[sh][e] * tab->N[sh][e][(size_t)m * N2 + n];
+    }
+    std::vector<double> out;
+    pack_tiles(out, M, 16 * MTU, cols, MTU, KSP + KST);
+    return out;
+  }
+  // weak divergence: six NP x 2NU blocks (see k_weak_div_mfma); broken != 0: the single block B
+  std::vector<double> pack_weakdiv_mfma(int sh, bool broken) const {
+    const int N2 = 2 * NU, KSU = sKSU(), cols = 4 * KSU;
+    auto E = [&](int e, int from) {  // (sigma_e / 2) Pt_e^T N_e[0:NL] with N of shape `from`
+      std::vector<double> M((size_t)16 * cols, 0.0);
+      for (int r = 0; r < NP; r++)
+        for (int n = 0; n < N2; n++) {
+          double acc = 0.0;
+          for (int m = 0; m < NL; m++) acc += tab->Pt[sh][e][(size_t)m * NP + r] * tab->N[from][e][(size_t)m * N2 + n];
+          M[(size_t)r * cols + scol(n)] = 0.5 * tab->sig[sh][e] * acc;
+        }
+      return M;
+    };
+    std::vector<double> out;
+    std::vector<double> base((size_t)16 * cols, 0.0);
+    const dvec& B0 = broken ? tab->B[sh] : tab->D0[sh];
+    for (int r = 0; r < NP; r++)
+      for (int n = 0; n < N2; n++) base[(size_t)r * cols + scol(n)] = B0[(size_t)r * N2 + n];
+    if (broken) { pack_tiles(out, base, 16, cols, 1, KSU); return out; }
+    const std::vector<double> E1 = E(1, sh);
+    for (size_t q = 0; q < base.size(); q++) base[q] += E1[q];
+    pack_tiles(out, base, 16, cols, 1, KSU);
+    pack_tiles(out, E(0, sh), 16, cols, 1, KSU);
+    pack_tiles(out, E(2, sh), 16, cols, 1, KSU);
+    pack_tiles(out, E(0, 1 - sh), 16, cols, 1, KSU);
+    pack_tiles(out, E(1, 1 - sh), 16, cols, 1, KSU);
+    pack_tiles(out, E(2, 1 - sh), 16, cols, 1, KSU);
+    return out;
+  }
+  const double *pgm[2] = {nullptr, nullptr}, *wdm[2] = {nullptr, nullptr}, *wdbm[2] = {nullptr, nullptr};
+  // HDG_NO_MFMA_SCHUR: the per-thread kernels at every degree (A/B timing, parity of the two formulations)
+  bool use_mfma_schur() const {
+    static const bool off = std::getenv("HDG_NO_MFMA_SCHUR") != nullptr;
+    return !off && cfg.degree >= mfma_min_degree() && !periodic;  // the matrix-core kernels do not wrap column indices
+  }
+  void ensure_schur_tables(PSet& ps) {
+    if (ps.bsm[0]) return;
+    // the device tables of a set mirror host data that is recomputed here (the host side keeps only the default set)
+    for (int sh = 0; sh < 2; sh++) {
+      dvec Ai, W_, Y_, SK_;
+      tab->poissonBlock(sh, ps.tau, Ai, W_, Y_, SK_);
+      ps.bsm[sh] = upload(pack_backsub_mfma(Ai, W_));
+      if (sh == 0) schur_Y0 = Y_; else ps.cdm = upload(pack_condense_mfma(schur_Y0, Y_));
+    }
+  }
+  dvec schur_Y0;
+  bool mfma_condense = std::getenv("HDG_MFMA_CONDENSE") != nullptr;  // per engine, not per process: tests build both
+  dim3 schur_cell_grid() const { return dim3(8 * g.rows_xcd * 2); }
+  dim3 schur_corner_grid() const { return dim3(8 * g.rows_xcdc); }
   const double* advm[2] = {nullptr, nullptr};
   const double* liftm_plain[2] = {nullptr, nullptr};  // packed tables of the plain BDM projection
   std::vector<double*> liftm_hyb0, liftm_hyb1;         // per stage: hybrid preconditioner
@@ -657,13 +821,14 @@ struct Engine {
     const int ext = stencil_in(in, FQ);
     const Geo gx = g_ext(ext);
     fl.set(out, ext);
+    tally(LC_LIFT, 2 * bQ());
     if (use_mfma_lift()) {
       if (!liftm_plain[0])
         for (int sh = 0; sh < 2; sh++) liftm_plain[sh] = upload(pack_lift_mfma(sh, tab->Lift[sh]));
       lift_mfma(gx, liftm_plain[0], liftm_plain[1], in, out);
       return;
     }
-    HDG_DISPATCH(k_edge_lift<KK, false, 0><<<cell_grid_of(gx), bs(), 0, stream>>>(gx, dt, in, out, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, 0.0, nullptr));
+    HDG_DISPATCH(k_edge_lift<KK, false, 0, false><<<cell_grid_of(gx), bs(), 0, stream>>>(gx, dt, in, out, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, 0.0, nullptr));
   }
   // rows a lift with the optional Chebyshev epilogue may compute (chd_ = x_{n-1} -> x_{n+1}, chx_ = x_n)
   int lift_ext(const double* in, const double* r, const double* chd_, const double* chx_, double c1) {
@@ -672,12 +837,19 @@ struct Engine {
     if (chd_) { ext = pw_in(chx_, ext); if (c1 != 0.0) ext = pw_in(chd_, ext); }
     return ext;
   }
+  // algorithmic bytes of a lift: reads in (+ r), writes out if given; Chebyshev epilogue: reads x_n (and x_{n-1} unless
+  // c1 == 0), writes x_{n+1}
+  double lift_bytes(bool has_r, bool has_out, bool cheb, double c1) const {
+    return bQ() * (1 + (has_r ? 1 : 0) + (has_out ? 1 : 0) + (cheb ? (c1 != 0.0 ? 3 : 2) : 0));
+  }
   // out = Pi(in) + Dinv r   (second half of the two-level preconditioner, block-Jacobi fused in)
   void bdm_plus_bj(const double* in, double* out, const double* r, const double* D0, const double* D1,
                    double* chd_ = nullptr, double* chx_ = nullptr, double c1 = 0.0, double c2 = 0.0) {
     const int ext = lift_ext(in, r, chd_, chx_, c1);
     const Geo gx = g_ext(ext);
-    HDG_DISPATCH(k_edge_lift<KK, false, 1><<<cell_grid_of(gx), bs(), 0, stream>>>(gx, dt, in, out, r, D0, D1, chd_, chx_, c1, c2, nullptr));
+    tally(LC_LIFT, lift_bytes(true, out != nullptr, chd_ != nullptr, c1));
+    if (chd_) { HDG_DISPATCH(k_edge_lift<KK, false, 1, true><<<cell_grid_of(gx), bs(), 0, stream>>>(gx, dt, in, out, r, D0, D1, chd_, chx_, c1, c2, nullptr)); }
+    else { HDG_DISPATCH(k_edge_lift<KK, false, 1, false><<<cell_grid_of(gx), bs(), 0, stream>>>(gx, dt, in, out, r, D0, D1, chd_, chx_, c1, c2, nullptr)); }
     fl.set(out, ext); fl.set(chd_, ext);
   }
   // hybrid two-level preconditioner in ONE kernel: out = Pi(in) + Dinv (in - Pi(in)) = in + sum_e G_e d_e(in),
@@ -691,17 +863,20 @@ struct Engine {
     // followed by the vector-kernel step; GMRES mode: the plain lift
     KTimed kt_(*this, T_KLIFT, fl.active() && (cfg.tent_solver == 1 ? (chd_ != nullptr || (use_mfma_lift() && out && !ss))
                                                                       : chd_ == nullptr));
+    tally(LC_LIFT, lift_bytes(false, out != nullptr, chd_ != nullptr, c1));
     if (use_mfma_lift() && out && !chd_ && !ss) {
       // GMRES path at k >= 3: no Chebyshev epilogue -> matrix-core kernel with the packed G tables of this stage
       for (size_t q = 0; q < hybg0.size(); q++)
         if (hybg0[q] == D0) { lift_mfma(gx, liftm_hyb0[q], liftm_hyb1[q], in, out); return; }
     }
-    HDG_DISPATCH(k_edge_lift<KK, false, 2><<<cell_grid_of(gx), bs(), 0, stream>>>(gx, dt, in, out, nullptr, D0, D1, chd_, chx_, c1, c2, ss));
+    if (chd_) { HDG_DISPATCH(k_edge_lift<KK, false, 2, true><<<cell_grid_of(gx), bs(), 0, stream>>>(gx, dt, in, out, nullptr, D0, D1, chd_, chx_, c1, c2, ss)); }
+    else { HDG_DISPATCH(k_edge_lift<KK, false, 2, false><<<cell_grid_of(gx), bs(), 0, stream>>>(gx, dt, in, out, nullptr, D0, D1, chd_, chx_, c1, c2, ss)); }
   }
   void bdm_T(const double* in, double* out) {
     const int ext = stencil_in(in, FQ);
     const Geo gx = g_ext(ext);
-    HDG_DISPATCH(k_edge_lift<KK, true, 0><<<cell_grid_of(gx), bs(), 0, stream>>>(gx, dt, in, out, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, 0.0, nullptr));
+    tally(LC_LIFT, 2 * bQ());
+    HDG_DISPATCH(k_edge_lift<KK, true, 0, false><<<cell_grid_of(gx), bs(), 0, stream>>>(gx, dt, in, out, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, 0.0, nullptr));
     fl.set(out, ext);
   }
   void adv_apply(const double* x, const double* qstar, double* out, double gamma, const double* bsub = nullptr) {
@@ -711,6 +886,7 @@ struct Engine {
     const dim3 cgrid = cell_grid_of(g);
     KTimed kt_(*this, T_KADV, fl.active() && ((cfg.tent_solver == 1) == (bsub != nullptr)));
     const double up = cfg.flux_upwind ? 1.0 : 0.0;
+    tally(LC_ADV, bQ() * (bsub ? 4 : 3));
     // k >= 3: the whole operator on the matrix cores (k_adv_mfma); HDG_NO_MFMA_ADV falls back to the per-thread kernels
     static const bool no_mfma_adv = std::getenv("HDG_NO_MFMA_ADV") != nullptr;
     if (!no_mfma_adv && cfg.degree >= mfma_min_degree() && !periodic) {
@@ -720,9 +896,15 @@ struct Engine {
       }
       const dim3 gridc(8 * g.rows_xcd * 2);
       if (dt.nqe != (3 * cfg.degree + 5) / 2) throw std::string("edge quadrature size does not match the matrix-core advection kernel");
-      if (cfg.degree == 2) k_adv_mfma<2><<<gridc, 512, 0, stream>>>(g, dt, advm[0], advm[1], x, qstar, out, gamma, up, bsub);
-      else if (cfg.degree == 3) k_adv_mfma<3><<<gridc, 512, 0, stream>>>(g, dt, advm[0], advm[1], x, qstar, out, gamma, up, bsub);
-      else k_adv_mfma<4><<<gridc, 512, 0, stream>>>(g, dt, advm[0], advm[1], x, qstar, out, gamma, up, bsub);
+      auto launch = [&](auto kk, auto res) {
+        constexpr int KK = decltype(kk)::value;
+        constexpr bool RS = decltype(res)::value;
+        k_adv_mfma<KK, RS><<<gridc, 512, 0, stream>>>(g, dt, advm[0], advm[1], x, qstar, out, gamma, up, bsub);
+      };
+      auto by_form = [&](auto kk) { if (bsub) launch(kk, std::true_type{}); else launch(kk, std::false_type{}); };
+      if (cfg.degree == 2) by_form(std::integral_constant<int, 2>{});
+      else if (cfg.degree == 3) by_form(std::integral_constant<int, 3>{});
+      else by_form(std::integral_constant<int, 4>{});
       return;
     }
     // k = 3: two lanes per cell, one velocity component each (k_adv_apply2).  Measured at nx = 512, one-lane vs
@@ -736,19 +918,45 @@ struct Engine {
       HDG_DISPATCH(k_adv_apply2<KK><<<dim3(8 * g.rows_xcd * 2 * nbx2), bs(), 0, stream>>>(g, dt, x, qstar, out, gamma, up, bsub));
       return;
     }
-    HDG_DISPATCH(k_adv_apply<KK><<<cgrid, bs(), 0, stream>>>(g, dt, x, qstar, out, gamma, up, bsub));
+    if (bsub) { HDG_DISPATCH(k_adv_apply<KK, true><<<cgrid, bs(), 0, stream>>>(g, dt, x, qstar, out, gamma, up, bsub)); }
+    else { HDG_DISPATCH(k_adv_apply<KK, false><<<cgrid, bs(), 0, stream>>>(g, dt, x, qstar, out, gamma, up, bsub)); }
   }
   void blockdiag(const double* D0, const double* D1, const double* r, const double* zin, double cz, double* out) {
+    tally(LC_LIFT, bQ() * (zin ? 3 : 2));
     HDG_DISPATCH(k_blockdiag<KK><<<cell_grid(), bs(), 0, stream>>>(g, D0, D1, r, zin, cz, out));
     fl.set(out, 0);
   }
   void pgrad(const double* a, double ca, const double* b, double cb, const double* p, const double* l, double gamma,
              double* out) {
     halo_L(l);
+    tally(LC_RHS, bQ() * (1 + (a ? 1 : 0) + (b ? 1 : 0)) + bP() + bL());
+    if (use_mfma_schur()) {
+      if (!pgm[0]) for (int sh = 0; sh < 2; sh++) pgm[sh] = upload(pack_pgrad_mfma(sh));
+      switch (K) {
+        case 2: k_pgrad_mfma<2><<<schur_cell_grid(), 64 * HDG_SCHUR_WAVES, 0, stream>>>(g, pgm[0], pgm[1], a, ca, b, cb, p, l, gamma, out); break;
+        case 3: k_pgrad_mfma<3><<<schur_cell_grid(), 64 * HDG_SCHUR_WAVES, 0, stream>>>(g, pgm[0], pgm[1], a, ca, b, cb, p, l, gamma, out); break;
+        default: k_pgrad_mfma<4><<<schur_cell_grid(), 64 * HDG_SCHUR_WAVES, 0, stream>>>(g, pgm[0], pgm[1], a, ca, b, cb, p, l, gamma, out); break;
+      }
+      return;
+    }
     HDG_DISPATCH(k_pgrad<KK><<<cell_grid(), bs(), 0, stream>>>(g, dt, a, ca, b, cb, p, l, gamma, out));
   }
   void weak_div(const double* q, double sc, double* out, bool broken) {
     if (!broken) halo_Q(q);
+    tally(LC_WDIV, bQ() + bP());
+    if (use_mfma_schur()) {
+      const double** tb = broken ? wdbm : wdm;
+      if (!tb[0]) for (int sh = 0; sh < 2; sh++) tb[sh] = upload(pack_weakdiv_mfma(sh, broken));
+      auto launch = [&](auto kk) {
+        constexpr int KK = decltype(kk)::value;
+        if (broken) k_weak_div_mfma<KK, true><<<schur_cell_grid(), 64 * HDG_SCHUR_WAVES, 0, stream>>>(g, tb[0], tb[1], q, sc, out);
+        else k_weak_div_mfma<KK, false><<<schur_cell_grid(), 64 * HDG_SCHUR_WAVES, 0, stream>>>(g, tb[0], tb[1], q, sc, out);
+      };
+      if (K == 2) launch(std::integral_constant<int, 2>{});
+      else if (K == 3) launch(std::integral_constant<int, 3>{});
+      else launch(std::integral_constant<int, 4>{});
+      return;
+    }
     if (broken) { HDG_DISPATCH(k_weak_div<KK, true><<<cell_grid(), bs(), 0, stream>>>(g, dt, q, sc, out)); }
     else { HDG_DISPATCH(k_weak_div<KK, false><<<cell_grid(), bs(), 0, stream>>>(g, dt, q, sc, out)); }
   }
@@ -756,6 +964,7 @@ struct Engine {
     int ext = std::min(stencil_in(lam, FL), max_ext);
     if (cb != 0.0) ext = pw_in(base, ext);
     const Geo c = g_ext(ext);
+    tally(LC_TRACE_APPLY, bL() * (2 + ((base && cb != 0.0) ? 1 : 0)));
     HDG_DISPATCH(k_trace_apply<KK><<<corner_grid_of(c), bs(), 0, stream>>>(c, pdt(), lam, base, cb, ct, out));
     fl.set(out, ext);
   }
@@ -766,6 +975,7 @@ struct Engine {
     if (cb != 0.0) ext = pw_in(base, ext);
     if (x && xadd) ext = pw_in(x, ext);
     const Geo c = g_ext(ext);
+    tally(LC_TRACE_SMOOTH, bL() * (1 + (base ? 1 : 0) + (r_out ? 1 : 0) + (d_out ? 1 : 0) + (x ? (xadd ? 2 : 1) : 0)));
     HDG_DISPATCH(k_trace_smooth<KK><<<corner_grid_of(c), bs(), 0, stream>>>(c, pdt(), v, base, cb, ct, c1, c2, r_out, d_out, x,
                                                                          xadd ? 1 : 0, xv));
     fl.set(r_out, ext); fl.set(d_out, ext); fl.set(x, ext);
@@ -775,6 +985,7 @@ struct Engine {
     if (c1 != 0.0) ext = pw_in(d, ext);
     if (x && !assign) ext = pw_in(x, ext);
     const Geo c = g_ext(ext);
+    tally(LC_TRACE_SMOOTH, bL() * (2 + (c1 != 0.0 ? 1 : 0) + (x ? (assign ? 1 : 2) : 0)));
     HDG_DISPATCH(k_trace_cheb<KK><<<corner_grid_of(c), bs(), 0, stream>>>(c, pdt(), r, d, x, c1, c2, assign ? 1 : 0));
     fl.set(d, ext); fl.set(x, ext);
   }
@@ -782,40 +993,85 @@ struct Engine {
   void p1_to_trace(const double* xc, double* z, double accumulate) {
     const int ext = accumulate != 0.0 ? pw_in(z, GH - 1) : (fl.active() ? fl.Dx - 1 : 0);
     const Geo c = g_ext(ext);
+    tally(LC_MG, bL() * (accumulate != 0.0 ? 2 : 1) + 8.0 * (g.nx + 1.0) * (g.ny + 1.0));
     k_p1_to_trace<<<corner_grid_of(c), bs(), 0, stream>>>(c, NL, xc, z, accumulate, dt.elen[0], dt.elen[2], dt.elen[1]);
     fl.set(z, ext);
   }
   void condense(const double* rw, const double* rp, const double* rl, double* out) {
     if (rw) halo_Q(rw);
     if (rp) halo_P(rp);
+    tally(LC_CONDENSE, (rw ? bQ() : 0.0) + (rp ? bP() : 0.0) + bL() * (rl ? 2 : 1));
+    // Condensation stays with the per-thread kernel by default: it is a gather over four cells per corner that already runs at
+    // 3.4-4.5 TB/s (512^2, us per launch, per-thread | matrix-core: pressure-row form k = 3 / 4: 15 / 21 | 31 / 46, velocity-row
+    // form 40 / 61 | 48 / 61).  HDG_MFMA_CONDENSE=1 (read when the engine is built) selects the matrix-core kernel.
+    if (mfma_condense && use_mfma_schur() && (rw || rp)) {
+      PSet& ps = psets[cur_pset];
+      ensure_schur_tables(ps);
+      auto launch = [&](auto kk, auto hw, auto hp) {
+        constexpr int KK = decltype(kk)::value;
+        k_condense_mfma<KK, decltype(hw)::value, decltype(hp)::value><<<schur_corner_grid(), 64 * HDG_SCHUR_WAVES, 0, stream>>>(g, ps.cdm, rw, rp, rl, out);
+      };
+      auto by_form = [&](auto kk) {
+        if (rw && !rp) launch(kk, std::true_type{}, std::false_type{});
+        else if (!rw && rp) launch(kk, std::false_type{}, std::true_type{});
+        else launch(kk, std::true_type{}, std::true_type{});
+      };
+      if (K == 2) by_form(std::integral_constant<int, 2>{});
+      else if (K == 3) by_form(std::integral_constant<int, 3>{});
+      else by_form(std::integral_constant<int, 4>{});
+      return;
+    }
     if (rw && !rp) { HDG_DISPATCH(k_condense<KK, true, false><<<corner_grid(), bs(), 0, stream>>>(g, pdt(), rw, rp, rl, out)); }
     else if (!rw && rp) { HDG_DISPATCH(k_condense<KK, false, true><<<corner_grid(), bs(), 0, stream>>>(g, pdt(), rw, rp, rl, out)); }
     else { HDG_DISPATCH(k_condense<KK, true, true><<<corner_grid(), bs(), 0, stream>>>(g, pdt(), rw, rp, rl, out)); }
   }
   void backsub(const double* rw, const double* rp, const double* lam, double* u, double* phi) {
     halo_L(lam);
+    tally(LC_BACKSUB, (rw ? bQ() : 0.0) + (rp ? bP() : 0.0) + bL() + bQ() + bP());
+    if (use_mfma_schur() && (rw || rp)) {
+      PSet& ps = psets[cur_pset];
+      ensure_schur_tables(ps);
+      auto launch = [&](auto kk, auto hw, auto hp) {
+        constexpr int KK = decltype(kk)::value;
+        k_backsub_mfma<KK, decltype(hw)::value, decltype(hp)::value><<<schur_cell_grid(), 64 * HDG_BACKSUB_WAVES, 0, stream>>>(g, ps.bsm[0], ps.bsm[1], rw, rp, lam, u, phi);
+      };
+      auto by_form = [&](auto kk) {
+        if (rw && !rp) launch(kk, std::true_type{}, std::false_type{});
+        else if (!rw && rp) launch(kk, std::false_type{}, std::true_type{});
+        else launch(kk, std::true_type{}, std::true_type{});
+      };
+      if (K == 2) by_form(std::integral_constant<int, 2>{});
+      else if (K == 3) by_form(std::integral_constant<int, 3>{});
+      else by_form(std::integral_constant<int, 4>{});
+      return;
+    }
     if (rw && !rp) { HDG_DISPATCH(k_backsub<KK, true, false><<<cell_grid(), bs(), 0, stream>>>(g, pdt(), rw, rp, lam, u, phi)); }
     else if (!rw && rp) { HDG_DISPATCH(k_backsub<KK, false, true><<<cell_grid(), bs(), 0, stream>>>(g, pdt(), rw, rp, lam, u, phi)); }
     else { HDG_DISPATCH(k_backsub<KK, true, true><<<cell_grid(), bs(), 0, stream>>>(g, pdt(), rw, rp, lam, u, phi)); }
   }
   void gamma_psi(const double* u, const double* phi, const double* lam, double* out) {
     if (lam) halo_L(lam);
+    tally(LC_OTHER, (u ? bQ() : 0.0) + (phi ? bP() : 0.0) + (lam ? bL() : 0.0) + bP());
     HDG_DISPATCH(k_gamma_psi<KK><<<cell_grid(), bs(), 0, stream>>>(g, dt, u, phi, lam, out));
   }
   void gamma_mu(const double* u, const double* phi, const double* lam, double* out) {
     if (u) halo_Q(u);
     if (phi) halo_P(phi);
+    tally(LC_OTHER, (u ? bQ() : 0.0) + (phi ? bP() : 0.0) + bL() * (lam ? 2 : 1));
     HDG_DISPATCH(k_gamma_mu<KK><<<corner_grid(), bs(), 0, stream>>>(g, dt, u, phi, lam, out));
   }
   void trace_recon(const double* Q, const double* p, double* out) {
     halo_Q(Q);
     halo_P(p);
+    tally(LC_OTHER, bQ() + bP() + bL());
     HDG_DISPATCH(k_trace_recon<KK><<<corner_grid(), bs(), 0, stream>>>(g, dt, Q, p, out));
   }
   void precon_rhs(const double* Q, const double* b, double bsc, double* rp, double* rl) {
     halo_Q(Q);
     halo_Q(b);
     HIPCHECK(hipMemsetAsync(rl, 0, sizeof(double) * NLv, stream));
+    tally(LC_COPY, bL());
+    tally(LC_RHS, 2 * bQ() + bP() + bL());
     HDG_DISPATCH(k_precon_rhs<KK><<<cell_grid(), bs(), 0, stream>>>(g, dt, Q, b, bsc, rp, rl));
   }
   void q_to_modal(const double* nodal, double* modal) { HDG_DISPATCH(k_q_nodal_to_modal<KK><<<cell_grid(), bs(), 0, stream>>>(g, dt, nodal, modal)); }
@@ -831,22 +1087,25 @@ struct Engine {
   // ------------------------------------------------------------------ vector helpers
   // (whole arrays, ghost rows included: a result is valid on the ghost rows all its inputs are valid on -- fl)
   void copy(double* dst, const double* src, long n) {
-    if (dst != src) HIPCHECK(hipMemcpyAsync(dst, src, sizeof(double) * n, hipMemcpyDeviceToDevice, stream));
+    if (dst != src) { HIPCHECK(hipMemcpyAsync(dst, src, sizeof(double) * n, hipMemcpyDeviceToDevice, stream)); tally(LC_COPY, 2 * bvec(n)); }
     fl.set(dst, fl.get(src));
   }
-  void zero(double* x, long n) { HIPCHECK(hipMemsetAsync(x, 0, sizeof(double) * n, stream)); fl.set(x, GH); }
+  void zero(double* x, long n) { HIPCHECK(hipMemsetAsync(x, 0, sizeof(double) * n, stream)); tally(LC_COPY, bvec(n)); fl.set(x, GH); }
   void axpby(long n, double a, const double* x, double b, double* y) {
+    tally(LC_VEC, bvec(n) * (b != 0.0 ? 3 : 2));
     if (big(n)) k_axpby<true><<<vec_blocks(n), 256, 0, stream>>>(n, a, x, b, y);
     else k_axpby<false><<<vec_blocks(n), 256, 0, stream>>>(n, a, x, b, y);
     fl.set(y, b == 0.0 ? fl.get(x) : std::min(fl.get(x), fl.get(y)));
   }
   void cheb_update(double* pn, const double* z, const double* x, double c1, double c2) {
+    tally(LC_VEC, bQ() * (c1 != 0.0 ? 4 : 3));
     if (big(NQ)) k_cheb_update<true><<<vec_blocks(NQ), 256, 0, stream>>>(NQ, pn, z, x, c1, c2);
     else k_cheb_update<false><<<vec_blocks(NQ), 256, 0, stream>>>(NQ, pn, z, x, c1, c2);
     fl.set(pn, std::min(std::min(fl.get(z), fl.get(x)), c1 != 0.0 ? fl.get(pn) : GH));
   }
   // out = scale * (w - sum_{l < nv} h_l V_l)   (V_l: the GMRES basis gm_V)
   void gs_update(const double* w, const Coefs& h, int nv, double scale, double* out) {
+    tally(LC_VEC, bQ() * (nv + 2));
     if (big(NQ)) k_gs_update<MAXV, true><<<vec_blocks(NQ), 256, 0, stream>>>(NQ, w, d_gmV, h, nv, scale, out);
     else k_gs_update<MAXV, false><<<vec_blocks(NQ), 256, 0, stream>>>(NQ, w, d_gmV, h, nv, scale, out);
     int d = fl.get(w);
@@ -870,6 +1129,7 @@ struct Engine {
       lc.n = 0;
       if (!first) { lc.v[0] = out; lc.c[0] = 1.0; lc.n = 1; }
       while (lc.n < 8 && off < t.size()) { lc.v[lc.n] = t[off].first; lc.c[lc.n] = t[off].second; lc.n++; off++; }
+      tally(LC_VEC, bvec(n) * (lc.n + 1));
       if (big(n)) k_lincomb<true><<<vec_blocks(n), 256, 0, stream>>>(n, lc, out);
       else k_lincomb<false><<<vec_blocks(n), 256, 0, stream>>>(n, lc, out);
       first = false;
@@ -902,6 +1162,8 @@ struct Engine {
       for (int q = 0; q < cnt && self < 0; q++) if (V[off + q] == w) self = q;
       const int cr = cross ? 1 : 0;
       const RowMask mk = mask_for(kind);
+      tally(LC_DOT, bvec(n) * (cnt + (self >= 0 ? 0 : 1)));
+      tally(LC_OTHER, 0.0);  // k_reduce_parts
       auto launch = [&](auto tag) {
         constexpr int MV = decltype(tag)::value;
         VecList<MV> vl;
@@ -936,6 +1198,9 @@ struct Engine {
     int nb = std::min(dot_blocks, vec_blocks(g.Nc));
     VecList<4> vl{};
     vl.p[0] = ones_c;
+    tally(LC_DOT, 2 * bvec(g.Nc));
+    tally(LC_OTHER, 0.0);
+    tally(LC_VEC, 2 * bvec(g.Nc) + (l ? 2 * bL() : 0.0));
     k_multidot<4, false><<<nb, HDG_DOT_BLOCK, 0, stream>>>(g.Nc, p, vl, 1, d_part, mask_for(KC), 0);
     k_reduce_parts<<<1, 256, 0, stream>>>(nb, 1, d_part, d_res);
     comm->allreduce_sum(d_res, 1, stream);
@@ -1166,6 +1431,7 @@ struct Engine {
         y[l] = acc / H[(size_t)l * m + l];
       }
       for (int l = 0; l < j; l++) yc.c[l] = y[l];
+      tally(LC_VEC, bQ() * (j + 2));
       if (big(NQ)) k_basis_axpy<MAXV, true><<<nvb, 256, 0, stream>>>(NQ, x, d_gmV, yc, j);
       else k_basis_axpy<MAXV, false><<<nvb, 256, 0, stream>>>(NQ, x, d_gmV, yc, j);
       {
@@ -1499,6 +1765,7 @@ struct Engine {
       long tot = 0;
       for (int l = lev; l < (int)mg_n.size() && tl.nlev < 8; l++) { tl.n[tl.nlev++] = mg_n[l]; tot += (long)(mg_n[l] + 1) * (mg_n[l] + 1); }
       if (tot <= HDG_P1_TAIL_MAX && lev + tl.nlev == (int)mg_n.size()) {
+        tally(LC_MG, 16.0 * tot);
         k_p1_vcycle_tail<<<1, 1024, 0, stream>>>(tl, mg_b[lev], mg_x[lev], nsw, ncoarse);
         return;
       }
@@ -1516,10 +1783,12 @@ struct Engine {
       const dim3 gt(nt, nt);
       auto down = [&](auto tag) {
         constexpr int NSW = decltype(tag)::value;
+        tally(LC_MG, 8.0 * nv * 2.25);  // reads b, writes the pre-smoothed x and the coarse right-hand side
         k_p1_down<NSW><<<gt, HDG_P1_THREADS, 0, stream>>>(n, mg_b[lev], mg_r[lev], mg_b[lev + 1]);
       };
       auto up = [&](auto tag) {
         constexpr int NSW = decltype(tag)::value;
+        tally(LC_MG, 8.0 * nv * 3.25);  // reads the coarse x, b, the pre-smoothed x, writes x
         k_p1_up<NSW><<<gt, HDG_P1_THREADS, 0, stream>>>(n, mg_x[lev + 1], mg_b[lev], mg_r[lev], mg_x[lev]);
       };
       if (nsw == 1) down(std::integral_constant<int, 1>{});
@@ -1569,7 +1838,7 @@ struct Engine {
     // halo of the level-0 right-hand side: lower message = rows J0 .. J0+40 (partial cut row first), upper = rows J1-40 .. J1
     const size_t nmsg = (size_t)(MG_HALO + 1) * st;
     comm->exchange(mg_b[0] + (long)J0 * st, hb_rlo, mg_b[0] + (long)(J1 - MG_HALO) * st, hb_rhi, nmsg, stream);
-    n_halo[1]++;
+    n_halo_mg++;
     k_p1_merge_halo<<<std::min(vec_blocks((long)nmsg), 256), 256, 0, stream>>>(st, MG_HALO, J0, J1, has_lo ? 1 : 0, has_hi ? 1 : 0,
                                                                              hb_rlo, hb_rhi, mg_b[0]);
     // tile rows of this rank (+ one on either side where a neighbour exists)
@@ -1631,6 +1900,7 @@ struct Engine {
       cheb_smooth(r, z, false, nsm);
       return;
     }
+    tally(LC_MG, bL() + 8.0 * (g.nx + 1.0) * (g.ny + 1.0));
     k_trace_to_p1<<<corner_grid_all(), bs(), 0, stream>>>(g_all, NL, wL2, mg_b[0], dt.elen[0], dt.elen[2], dt.elen[1], partial);
     if (mg_distributed()) {
       vcycle_distributed_top();
@@ -1762,6 +2032,7 @@ struct Engine {
     dots_and_snapshot(1);
     const double norm0 = std::sqrt(std::max(snapshot_norm2(true), 0.0));
     if (norm0 == 0.0) return 0;
+    tally(LC_VEC, bL() * 3);
     k_cg_p_dev<<<nvb, 256, 0, stream>>>(NLv, cg_z, tr_one, d_cgs, cg_p);
     fl.set(cg_p, 0);
     int its = 0;
@@ -1778,12 +2049,14 @@ struct Engine {
           return its;
         }
       }
+      tally(LC_VEC, bL() * 6);
       k_cg_xr_dev<<<nvb, 256, 0, stream>>>(NLv, d_cgs, cg_p, cg_Ap, x, cg_r);  // whole arrays: ghost rows follow
       fl.set(cg_r, std::min(fl.get(cg_r), fl.get(cg_Ap)));
       fl.set(x, 0);
       trace_precond(cg_r, cg_z);
       dots_and_snapshot(0);
       its++;
+      tally(LC_VEC, bL() * 4);
       k_cg_p_dev<<<nvb, 256, 0, stream>>>(NLv, cg_z, tr_one, d_cgs, cg_p);
       fl.set(cg_p, 0);
     }
@@ -1808,6 +2081,8 @@ struct Engine {
       trace_precond(cg_r, cg_z);
       trace_apply(cg_z, nullptr, 0.0, 1.0, cg_Ap);  // w = T z
       multidot(NLv, cg_z, {tr_one, cg_r, cg_z, cg_Ap}, nullptr, KL, true);  // (z,n), (z,r), (z,z), (z,w), (n,r) -> d_res
+      tally(LC_OTHER, 0.0);
+      tally(LC_VEC, bL() * 11);  // k_cg_sr_update: reads z, n, w, p, s, x, r; writes p, s, x, r
       k_cg_sr_scalars<<<1, 1, 0, stream>>>(d_res, d_cgs, tr_one_nn, its == 0 ? 1 : 0);
       HIPCHECK(hipMemcpyAsync(h_cgs, d_cgs, sizeof(double) * 8, hipMemcpyDeviceToHost, stream));
       HIPCHECK(hipEventRecord(cg_ev, stream));
@@ -2109,10 +2384,9 @@ struct Engine {
       cg_project(curQ, uproj);
       tracer_adv(q_cur, uproj, q_t);
     }
-    struct TracerEnd {  // hdg_implicit.py:192-193, on every return path of this function
-      Engine& E; double dtt;
-      ~TracerEnd() { if (E.tracer_on) E.axpby(E.NPv, dtt, E.q_t, 1.0, E.q_cur); }
-    } tracer_end_{*this, dtt};
+    // hdg_implicit.py:192-193: the tracer is advanced only after a SUCCESSFUL step (a failed Krylov solve must leave it
+    // where Q and p stay), so the update sits before each of the two normal returns, not in a scope guard
+    auto tracer_end = [&]() { if (tracer_on) axpby(NPv, dtt, q_t, 1.0, q_cur); };
     ensure_dinv(0, dtt);
     { Timed tb_(*this, T_BDM); bdm(curQ, Qstar[0]); }             // hdg_implicit.py:98
     if (!cfg.use_projection) {
@@ -2129,6 +2403,7 @@ struct Engine {
       shift(curP, curL);
       if (its_t) *its_t = it;
       if (its_p) *its_p = 0;
+      tracer_end();
       return;
     }
     // rhs lives in updU: wQ1..wQ4 are scratch of GMRES and its preconditioner
@@ -2154,6 +2429,7 @@ struct Engine {
     shift(curP, curL);                                           // hdg_implicit.py:189-190
     if (its_t) *its_t = it1;
     if (its_p) *its_p = it2;
+    tracer_end();
   }
 
 
@@ -2469,7 +2745,9 @@ struct Engine {
   // 2 BDM projection, 3 back-substitution, 4 additive preconditioner + Chebyshev step, 5 transposed lift,
   // 6 hybrid preconditioner + Chebyshev step (per-thread lift kernel), 7 advection operator in residual form,
   // 8 stream triad on velocity vectors, 9 hybrid preconditioner alone (the GMRES path: matrix-core lift at k >= 3)
-  static constexpr int N_TIME_KERNELS = 10;
+  // 10 condensation (pressure-row form), 11 pressure-gradient combination, 12 weak divergence, 13 reconstruction rhs
+  // 14 condensation (velocity-row form of the final stage)
+  static constexpr int N_TIME_KERNELS = 15;
   double time_kernel(int kernel, int reps) {
     if (kernel < 0 || kernel >= N_TIME_KERNELS) throw std::string("unknown kernel id");  // before any state is touched
     // halo exchanges are switched off for the bare launches (the call is not collective); restored on EVERY exit path
@@ -2508,6 +2786,11 @@ struct Engine {
           ensure_dinv(1 % s, 0.25 * cfg.dt);
           bdm_hybrid(wQ2, wQ1, hybg0[1 % s], hybg1[1 % s]);
           break;
+        case 10: condense(nullptr, curP, nullptr, wL1); break;
+        case 11: pgrad(wQ3, 1.0, wQ4, -1.0, curP, curL, 0.25 * cfg.dt, wQ1); break;
+        case 12: weak_div(curQ, 1.0, wP1, false); break;
+        case 13: precon_rhs(curQ, wQ2, 1.0, wP1, wL2); break;
+        case 14: condense(curQ, nullptr, nullptr, wL1); break;
         default: throw std::string("unknown kernel id");
       }
     };
@@ -2780,6 +3063,7 @@ int hdg_run_separable(hdg_handle* h, int nsteps, const double* scales) {
   for (int n = 0; n < nsteps; n++) {
     for (int sl = 0; sl <= E.s; sl++) { E.bscale[sl] = scales[(long)n * (E.s + 1) + sl]; E.bsep[sl] = 1; }
     E.step();
+    E.harvest_completed();  // keeps the number of live timer events bounded over a long run
   }
   HDG_API_END(h)
 }
@@ -2808,6 +3092,16 @@ int hdg_get_timers(hdg_handle* h, double* total_ms, double* sumsq_ms, long* ncal
     if (reset) { E.tm_total[i] = 0; E.tm_sumsq[i] = 0; E.tm_calls[i] = 0; }
   }
   HDG_API_END(h)
+}
+int hdg_get_launch_stats(hdg_handle* h, long* calls, double* bytes, int reset) {
+  if (!h || !h->eng) return HDG_ERR_ARG;
+  hdg::Engine& E = *h->eng;
+  for (int i = 0; i < HDG_N_LAUNCH_CLASSES; i++) {
+    if (calls) calls[i] = E.lc_calls[i];
+    if (bytes) bytes[i] = E.lc_bytes[i];
+    if (reset) { E.lc_calls[i] = 0; E.lc_bytes[i] = 0.0; }
+  }
+  return HDG_OK;
 }
 int hdg_set_kernel_timing(hdg_handle* h, int on) {
   HDG_API_BEGIN(h)

@@ -290,14 +290,16 @@ __device__ __forceinline__ void mv_acc_ld(const double* __restrict__ A, int LD, 
 #ifndef HDG_LIFT_WAVES
 #define HDG_LIFT_WAVES 1
 #endif
-template <int K, bool TRANSPOSE, int ADD_BJ>
+// CHEB (compile time) = with the Chebyshev epilogue: its own instantiation and kernel NAME (profiles, counters).
+template <int K, bool TRANSPOSE, int ADD_BJ, bool CHEB>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(HDG_LIFT_WAVES)))
 void k_edge_lift(Geo g, DevTables T, const double* __restrict__ in,
                                                     double* __restrict__ out, const double* __restrict__ r,
                                                     const double* __restrict__ Dinv0, const double* __restrict__ Dinv1,
-                                                    double* __restrict__ chd, double* __restrict__ chx, double c1,
+                                                    double* __restrict__ chd_, double* __restrict__ chx, double c1,
                                                     double c2, double* __restrict__ cell_ss) {
   constexpr int NU = Dim<K>::NU, NE = Dim<K>::NE, N2 = 2 * NU;
+  double* __restrict__ chd = CHEB ? chd_ : nullptr;
   HDG_CELL_PROLOGUE
   double y[N2], down[3][NE];
   load_vel<NU>(in, g.Nc, c, y);
@@ -391,25 +393,44 @@ void k_edge_lift(Geo g, DevTables T, const double* __restrict__ in,
 // wave w the tiles w, w+8, ...
 // ------------------------------------------------------------------------------------------
 typedef double hdg_v4d __attribute__((ext_vector_type(4)));
+// 16-byte access of the mode-m pair of cell c with a LANE-dependent mode (the plane offset goes into the vector offset;
+// stores keep soffset = 0, the hazard-safe form: VelBuf::st)
+template <int NU>
+__device__ __forceinline__ hdg_d2 ld_pair_lane(const VelBuf& B, long Nc, long c, int m) {
+  if (m >= NU) return hdg_d2{0.0, 0.0};
+  return __builtin_bit_cast(hdg_d2, __builtin_amdgcn_raw_buffer_load_b128(B.r, (unsigned)(((unsigned long)m * (unsigned long)Nc + (unsigned long)c) * 16ul), 0, 0));
+}
+__device__ __forceinline__ void st_pair_lane(const VelBuf& B, long Nc, long c, int m, hdg_d2 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(hdg_u32x4, v), B.r, (unsigned)(((unsigned long)m * (unsigned long)Nc + (unsigned long)c) * 16ul), 0, 0);
+}
+
 // double index of velocity dof kappa = 2m + d of cell c (memory order of the component-pair layout)
 __device__ __forceinline__ long kix(int kappa, long Nc, long c) { return (((long)(kappa >> 1) * Nc + c) << 1) + (kappa & 1); }
 template <int K>
 struct LiftMfma {
   static constexpr int NU = Dim<K>::NU, NE = Dim<K>::NE, N2 = 2 * NU;
-  static constexpr int KS = (N2 + 3) / 4;    // K-steps over the coefficient planes
-  static constexpr int MT = (N2 + 15) / 16;  // M-tiles of the result
+  static constexpr int KQ = (NU + 3) / 4;    // K-step PAIRS over the coefficient planes (one 16-byte pair load each)
+  static constexpr int KS = 2 * KQ;          // K-steps over the coefficient planes
+  static constexpr int MT = (NU + 7) / 8;    // M-tiles of the result (8 modes = 16 rows each)
   static constexpr int KD = 5;               // K-steps over the packed moments: 3 (tile 0, rows 0..11) + 2 (tile 1, rows 0..7)
   static constexpr int NTILES = 2 * KS + 3 * KS + MT * KD;  // W (2 M-tiles), N'_e (3), G
   static_assert(2 * NE <= 12 && NE <= 8, "packed moment rows do not fit the K-steps");
+  static_assert(2 * MT <= KQ + 1, "result tiles must map onto the loaded pairs");
 };
 #ifndef HDG_LIFT_MFMA_WAVES
 #define HDG_LIFT_MFMA_WAVES 8
 #endif
+// Velocity dofs <-> K slots / result rows (round 3): 16-BYTE accesses.  K-steps come in pairs (2q, 2q+1): lane (lk, li)
+// loads the pair of mode 4q + lk of cell li with one buffer_load_dwordx4 and feeds .x to K-step 2q, .y to 2q+1; result tile
+// mt holds modes 8 mt .. 8 mt + 7 with both components of mode 8 mt + lk in accumulator registers 0, 1 and of mode
+// 8 mt + 4 + lk in 2, 3 -- the SAME pairs (q = 2 mt, 2 mt + 1), so the loaded own coefficients are B operands and
+// accumulator start values at once, and a tile is stored with two buffer_store_dwordx4 (Engine::scol / srow pack the
+// tables accordingly).  Before: 8-byte accesses in memory order, 56 loads + 12 stores per cell tile; now 24 + 6.
 template <int K>
 __global__ __launch_bounds__(64 * HDG_LIFT_MFMA_WAVES) void k_edge_lift_mfma(Geo g, const double* __restrict__ tabs0, const double* __restrict__ tabs1,
                                                          const double* __restrict__ in, double* __restrict__ out) {
   typedef LiftMfma<K> L;
-  constexpr int NE = L::NE, N2 = L::N2, KS = L::KS, MT = L::MT, KD = L::KD;
+  constexpr int NU = L::NU, NE = L::NE, KQ = L::KQ, KS = L::KS, MT = L::MT, KD = L::KD;
   __shared__ double tab[L::NTILES * 64];
   // per-wave slab for the moments: rows 0..11 = tile 0 (edges 0, 1), rows 12..19 = tile 1 rows 0..7 (edge 2)
   __shared__ double dst[HDG_LIFT_MFMA_WAVES][20][16];
@@ -425,12 +446,14 @@ __global__ __launch_bounds__(64 * HDG_LIFT_MFMA_WAVES) void k_edge_lift_mfma(Geo
   const double* __restrict__ tW = tab;                     // [2][KS][64]
   const double* __restrict__ tN = tab + 2 * KS * 64;       // [3][KS][64]
   const double* __restrict__ tG = tab + 5 * KS * 64;       // [MT][KD][64]
+  const VelBuf Bin(in), Bout(out);
   const int gj = g.joff + j;
   const bool has0 = s == 0 ? gj > 0 : gj < g.nyg - 1;
   const int jn0 = s == 0 ? j - 1 : j + 1;
   const long rowN0 = rowbase(g, 1 - s, jn0), rowN = rowbase(g, 1 - s, j);
   const long rowC = rowbase(g, s, j);
   const int ntx = (g.nx + 15) >> 4;
+  const hdg_d2 zero2 = {0.0, 0.0};
   for (int tx = w; tx < ntx; tx += HDG_LIFT_MFMA_WAVES) {
     const int i = tx * 16 + li;
     const bool col = i < g.nx;
@@ -438,26 +461,31 @@ __global__ __launch_bounds__(64 * HDG_LIFT_MFMA_WAVES) void k_edge_lift_mfma(Geo
     const bool has2 = s == 0 ? i > 0 : i < g.nx - 1;
     const int i2 = s == 0 ? ic - 1 : ic + 1;
     const long c = rowC + ic, cn0 = rowN0 + ic, cn1 = rowN + ic, cn2 = rowN + (has2 ? i2 : ic);
-    // (1) own moments
+    // all coefficient pairs of the tile: own cell and the three neighbours (a missing neighbour contributes zeros)
+    hdg_d2 xo[KQ], x0[KQ], x1[KQ], x2[KQ];
+#pragma unroll
+    for (int q = 0; q < KQ; q++) {
+      const int m = 4 * q + lk;
+      xo[q] = ld_pair_lane<NU>(Bin, g.Nc, c, m);
+      x0[q] = has0 ? ld_pair_lane<NU>(Bin, g.Nc, cn0, m) : zero2;
+      x1[q] = ld_pair_lane<NU>(Bin, g.Nc, cn1, m);
+      x2[q] = has2 ? ld_pair_lane<NU>(Bin, g.Nc, cn2, m) : zero2;
+    }
+    // (1) own moments, (2) neighbours: edges 0, 1 -> tile 0, edge 2 -> tile 1
     hdg_v4d D0 = {0, 0, 0, 0}, D1 = {0, 0, 0, 0};
 #pragma unroll
     for (int ks = 0; ks < KS; ks++) {
-      const int n = 4 * ks + lk;
-      const double b = (n < N2) ? in[kix(n, g.Nc, c)] : 0.0;
+      const int q = ks >> 1;
+      const double b = (ks & 1) ? xo[q].y : xo[q].x;
       D0 = __builtin_amdgcn_mfma_f64_16x16x4f64(tW[(0 * KS + ks) * 64 + l], b, D0, 0, 0, 0);
       D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(tW[(1 * KS + ks) * 64 + l], b, D1, 0, 0, 0);
     }
-    // (2) neighbours: edges 0, 1 -> tile 0, edge 2 -> tile 1 (a missing neighbour contributes zeros)
 #pragma unroll
     for (int ks = 0; ks < KS; ks++) {
-      const int n = 4 * ks + lk;
-      const bool nv = n < N2;
-      const double b0 = (nv && has0) ? in[kix(n, g.Nc, cn0)] : 0.0;
-      const double b1 = nv ? in[kix(n, g.Nc, cn1)] : 0.0;
-      const double b2 = (nv && has2) ? in[kix(n, g.Nc, cn2)] : 0.0;
-      D0 = __builtin_amdgcn_mfma_f64_16x16x4f64(tN[(0 * KS + ks) * 64 + l], b0, D0, 0, 0, 0);
-      D0 = __builtin_amdgcn_mfma_f64_16x16x4f64(tN[(1 * KS + ks) * 64 + l], b1, D0, 0, 0, 0);
-      D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(tN[(2 * KS + ks) * 64 + l], b2, D1, 0, 0, 0);
+      const int q = ks >> 1;
+      D0 = __builtin_amdgcn_mfma_f64_16x16x4f64(tN[(0 * KS + ks) * 64 + l], (ks & 1) ? x0[q].y : x0[q].x, D0, 0, 0, 0);
+      D0 = __builtin_amdgcn_mfma_f64_16x16x4f64(tN[(1 * KS + ks) * 64 + l], (ks & 1) ? x1[q].y : x1[q].x, D0, 0, 0, 0);
+      D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(tN[(2 * KS + ks) * 64 + l], (ks & 1) ? x2[q].y : x2[q].x, D1, 0, 0, 0);
     }
     // weights: 1/2 where the neighbour exists.  Accumulator layout (measured): lane (lk, li) register r holds
     // row lk + 4 r of column li
@@ -478,18 +506,14 @@ __global__ __launch_bounds__(64 * HDG_LIFT_MFMA_WAVES) void k_edge_lift_mfma(Geo
     for (int kd = 0; kd < KD; kd++) bd[kd] = dst[w][4 * kd + lk][li];  // K index q: 0..11 tile 0, 12..19 tile 1
 #pragma unroll
     for (int mt = 0; mt < MT; mt++) {
-      hdg_v4d Y;
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int n = 16 * mt + lk + 4 * r;
-        Y[r] = (n < N2) ? in[kix(n, g.Nc, c)] : 0.0;
-      }
+      const hdg_d2 lo = xo[2 * mt], hi = (2 * mt + 1 < KQ) ? xo[(2 * mt + 1 < KQ) ? 2 * mt + 1 : 0] : zero2;
+      hdg_v4d Y = {lo.x, lo.y, hi.x, hi.y};
 #pragma unroll
       for (int kd = 0; kd < KD; kd++) Y = __builtin_amdgcn_mfma_f64_16x16x4f64(tG[(mt * KD + kd) * 64 + l], bd[kd], Y, 0, 0, 0);
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int n = 16 * mt + lk + 4 * r;
-        if (n < N2 && col) out[kix(n, g.Nc, c)] = Y[r];
+      if (col) {
+        const int m0 = 8 * mt + lk, m1 = m0 + 4;
+        if (m0 < NU) st_pair_lane(Bout, g.Nc, c, m0, hdg_d2{Y[0], Y[1]});
+        if (m1 < NU) st_pair_lane(Bout, g.Nc, c, m1, hdg_d2{Y[2], Y[3]});
       }
     }
   }
@@ -554,12 +578,15 @@ __device__ __forceinline__ void adv_facet(const DevTables& T, int s, int e, bool
 #ifndef HDG_ADV_PIPE
 #define HDG_ADV_PIPE 1
 #endif
-template <int K>
+// RESID (compile time) = the residual form b - A x: a separate instantiation, so that profiles and counters tell the two
+// forms of the kernel apart by NAME (k_adv_apply<2, true> reads 3 vectors and writes 1, <2, false> reads 2).
+template <int K, bool RESID>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(HDG_ADV_WAVES)))
 void k_adv_apply(Geo g, DevTables T, const double* __restrict__ xin,
                                                     const double* __restrict__ qstar, double* __restrict__ out,
-                                                    double gamma, double upwind, const double* __restrict__ bsub) {
+                                                    double gamma, double upwind, const double* __restrict__ bsub_) {
   constexpr int NU = Dim<K>::NU, N2 = 2 * NU;
+  const double* __restrict__ bsub = RESID ? bsub_ : nullptr;
   HDG_CELL_PROLOGUE
   double x[N2], qs[N2], F[N2];
   load_vel<NU>(xin, g.Nc, c, x);
@@ -783,12 +810,13 @@ struct AdvMfmaFull {
   static constexpr int OFF_EN = OFF_EQY + 2 * KSU, OFF_ET = OFF_EN + 3 * KSU, NTILES = OFF_ET + MTU * 6;
   static_assert(NQE <= 8, "edge rule does not fit the 8-row packing");
 };
-template <int K>
+template <int K, bool RESID>  // RESID: residual form b - A x (own kernel name, see k_adv_apply)
 __global__ __launch_bounds__(512) void k_adv_mfma(Geo g, DevTables T, const double* __restrict__ tabs0,
                                                    const double* __restrict__ tabs1, const double* __restrict__ xin,
                                                    const double* __restrict__ qstar, double* __restrict__ out, double gamma,
-                                                   double upwind, const double* __restrict__ bsub) {
+                                                   double upwind, const double* __restrict__ bsub_) {
   typedef AdvMfmaFull<K> A;
+  const double* __restrict__ bsub = RESID ? bsub_ : nullptr;
   constexpr int NU = A::NU, MTQ = A::MTQ, KSU = A::KSU, MTU = A::MTU, NT1 = A::NT1, NQE = A::NQE;
   __shared__ double tab[A::NTILES * 64];
   __shared__ double slab[8][2][24][16];

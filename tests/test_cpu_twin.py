@@ -67,3 +67,55 @@ def test_cpu_twin_steps_match_the_numpy_oracle(k, nx, tableau, R):
     assert _rel(Q, oQ) < TOL and _rel(p, op) < TOL and _rel(lam, o.lam) < TOL
     sums, cnt = t.iteration_stats()
     assert np.all(cnt > 0) and np.all(sums / cnt < 80)
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 4])
+def test_shared_tables_give_the_oracle_matrices_entry_by_entry(k):
+    """The twin shares ONE file with the product: the host tables csrc/hdg_tables.hpp (bases, quadrature, local matrices).
+    The large-mesh twin-vs-GPU comparisons (tests/test_gpu_cpu_twin.py) therefore cannot see a table error.  This test
+    can: every operator the tables feed is probed with unit vectors on a 2 x 2 mesh (8 cells: both shapes, interior and
+    boundary edges of every orientation) and the resulting global matrices are compared ENTRY BY ENTRY with the numpy
+    oracle's independently assembled nodal matrices -- BDM projection (N, Lift), advection operator for both fluxes
+    (cell / edge tabulations, quadrature weights, normals, penalty), weak divergence (D0, N, Pt), condensed trace operator
+    (A^-1, W, Y, S_K) -- at every degree the product supports, k = 4 included."""
+    import scipy.sparse as sp
+
+    from oracle.hdg_oracle import HDGDiscretisation
+
+    nx = 2
+    d = HDGDiscretisation(nx, k)
+    t = _twin(k, nx)
+    nq = int(np.prod(t.shape_Q))
+    eye_q = np.eye(nq)
+
+    def columns(fn, n, shape):
+        return np.stack([np.asarray(fn(col.reshape(shape))).ravel() for col in np.eye(n)], axis=1)
+
+    # BDM projection: a linear map on the nodal velocity vector
+    P_twin = columns(t.project_bdm_nodal, nq, t.shape_Q)
+    P_ref = np.stack([d.project_bdm(eye_q[:, c].reshape(t.shape_Q)).ravel() for c in range(nq)], axis=1)
+    assert np.max(np.abs(P_twin - P_ref)) < 1e-11 * max(1.0, np.max(np.abs(P_ref)))
+    # advection operator I - gamma M^-1 F(Q*) for a fixed random conforming Q*
+    rng = np.random.default_rng(11)
+    Qstar = d.project_bdm(rng.standard_normal(t.shape_Q))
+    Mi = spla.splu(d.MQ.tocsc())
+    gamma = 0.2 / nx
+    for flux in ("upwind", "centered"):
+        tf = _twin(k, nx, flux=flux)
+        A_twin = columns(lambda x: tf.apply_advection(Qstar, x, gamma), nq, t.shape_Q)
+        A_ref = np.eye(nq) - gamma * Mi.solve(d.assemble_f_impl(Qstar, flux).toarray())
+        assert np.max(np.abs(A_twin - A_ref)) < 5e-11 * np.max(np.abs(A_ref)), flux
+    # weak divergence
+    W_twin = columns(t.apply_weak_divergence, nq, t.shape_Q)
+    W_ref = spla.splu(d.MP.tocsc()).solve(d.Wdiv.toarray())
+    assert np.max(np.abs(W_twin - W_ref)) < 1e-11 * np.max(np.abs(W_ref))
+    # condensed trace operator -S in the Riesz representation of the orthonormal edge basis (single edge mass matrix)
+    n1 = d.NQ + d.NP
+    Kmp = d.K_mp.tocsc()
+    S = Kmp[n1:, n1:].toarray() - Kmp[n1:, :n1] @ spla.splu(Kmp[:n1, :n1].tocsc()).solve(Kmp[:n1, n1:].toarray())
+    mult = np.where(np.repeat(d.mesh.interior, d.nl), 2.0, 1.0)
+    Mtr = (sp.diags(1.0 / mult) @ (d.Lm.tocsc() / d.tau)).tocsc()
+    T_ref = spla.splu(Mtr).solve(-S)
+    nl = int(np.prod(t.shape_l))
+    T_twin = columns(t.apply_trace_operator, nl, t.shape_l)
+    assert np.max(np.abs(T_twin - T_ref)) < 1e-10 * np.max(np.abs(T_ref))

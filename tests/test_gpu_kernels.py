@@ -175,7 +175,7 @@ def test_time_kernel_ids_and_errors(hip_lib):
         d, e = _setup(2, 16, tent_precond=tp)
         rng = np.random.default_rng(5)
         e.set_state(rng.standard_normal(e.shape_Q), rng.standard_normal(e.shape_p))
-        for kid in range(10):
+        for kid in range(15):
             ms = e.time_kernel(kid, 3)
             assert 0.0 < ms < 50.0, (tp, kid, ms)
         with pytest.raises(_lib.HDGError):
@@ -248,3 +248,79 @@ def test_matrix_core_kernels_at_k2_behind_the_switch(hip_lib):
     ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, HDG_MFMA_K2="1"), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("mfma_condense", [False, True])
+@pytest.mark.parametrize("k,nx", [(3, 20), (4, 18)])
+def test_schur_matrix_core_kernels_tiles(hip_lib, k, nx, mfma_condense, monkeypatch):
+    """The GEMM-shaped Schur kernels (hdg_schur_mfma.hpp: k_backsub_mfma, k_condense_mfma, k_pgrad_mfma,
+    k_weak_div_mfma; default at k >= 3, BASELINE C4 / C5) own 16 consecutive cells / corners per wave: meshes with a full
+    and a partial tile per row (the small meshes of the other tests have partial tiles only).  One stage iteration, the
+    final stage and the pressure reconstruction of an HDG-IMEX step, piece by piece against the oracle's direct solves
+    (hdg_imex.py:239-247 tentative right-hand side with the pressure gradient, :177-179 weak divergence, :128-135 SCPC
+    elimination / back-substitution in all three right-hand-side forms, :201-207 with the boundary term)."""
+    from incompressibleeulerhdg_amd import _lib
+    from oracle import hdg_oracle as orc
+
+    # condensation runs on the per-thread kernel by default (it is the faster one); HDG_MFMA_CONDENSE, read when an engine is
+    # built, selects k_condense_mfma
+    if mfma_condense:
+        monkeypatch.setenv("HDG_MFMA_CONDENSE", "1")
+    else:
+        monkeypatch.delenv("HDG_MFMA_CONDENSE", raising=False)
+    d, e = _setup(k, nx)
+    dt = 0.25 / nx
+    o = orc.OracleHDGIMEX(d, dt, "imex_ssp2_332")
+    rng = np.random.default_rng(40 + k)
+    TOL = 2e-8  # two converged solvers (SURVEY.md section 8c)
+    # operators first: weak divergence in both forms (hdg_imex.py:353-365; hdg_implicit.py:145)
+    Qr = rng.standard_normal(e.shape_Q)
+    Mi = spla.splu(d.MP.tocsc())
+    assert _relerr(e.apply_weak_divergence(Qr), Mi.solve(d.Wdiv @ Qr.ravel())) < RTOL
+    assert _relerr(e.apply_weak_divergence(Qr, broken=True), Mi.solve(d.Bdiv @ Qr.ravel())) < RTOL
+    # state: current fields, persistent stage iterates, nodal forcing in every slot
+    Q0, p0 = rng.standard_normal(e.shape_Q), rng.standard_normal(e.shape_p)
+    e.set_state(Q0, p0)
+    e.reconstruct_trace()
+    o.set_initial_condition(Q0, p0)
+    for i in (1, 2):
+        o.stage_Q[i], o.stage_p[i], o.stage_l[i] = (rng.standard_normal(e.shape_Q), rng.standard_normal(e.shape_p),
+                                                    rng.standard_normal(e.shape_l))
+        e.set_field(i, o.stage_Q[i], o.stage_p[i], o.stage_l[i])
+    for sl in range(3):
+        o.b_rhs[sl] = rng.standard_normal(e.shape_Q)
+        e.set_forcing_nodal(sl, o.b_rhs[sl])
+    b_new = rng.standard_normal(e.shape_Q)
+    e.set_forcing_nodal(3, b_new)
+    e.begin_step()
+    o.stage_Q[0], o.stage_p[0], o.stage_l[0] = o.Q.copy(), o.p.copy(), o.lam.copy()
+    # stage 1, one Richardson iteration: tentative velocity (k_pgrad_mfma builds its right-hand side) ...
+    e.project_bdm(0, 0)
+    Qstar = d.project_bdm(o.stage_Q[0])
+    adt = o.a_impl[1, 1] * dt
+    F = d.assemble_f_impl(Qstar, "upwind")
+    Qi = o.stage_Q[1].ravel()
+    rhs = o._residual(1) - d.MQ @ Qi + adt * (F @ Qi + d.G_p @ o.stage_p[1] + d.G_l @ o.stage_l[1])
+    dQ = spla.splu((d.MQ - adt * F).tocsc()).solve(rhs)
+    e.tentative_solve(1)
+    assert _relerr(e.get_field(101, p=False, lam=False)[0].ravel(), dQ) < TOL
+    # ... and its pressure correction (k_weak_div_mfma, k_condense_mfma<.,false,true>, k_backsub_mfma<.,false,true>)
+    du, dp, dl = d.solve_mixed_poisson(rP=-(1.0 / adt) * (d.Wdiv @ dQ))
+    dp, dl = d.shift_pressure(dp, dl)
+    e.pressure_solve(1)
+    e.shift_pressure(_lib.HDG_STATE_UPDATE)
+    gu, gp, gl = e.get_field(_lib.HDG_STATE_UPDATE)
+    assert _relerr(gu.ravel(), du) < TOL and _relerr(gp, dp) < TOL and _relerr(gl, dl) < TOL
+    # final stage: velocity-row right-hand side (k_condense_mfma<.,true,false>, k_backsub_mfma<.,true,false>)
+    u, _, _ = d.solve_mixed_poisson(rQ=o._final_residual())
+    e.pressure_solve(_lib.HDG_KEY_FINAL_STAGE)
+    gQ = e.get_field(_lib.HDG_STATE_CURRENT, p=False, lam=False)[0]
+    assert _relerr(gQ.ravel(), u) < TOL
+    # pressure reconstruction: pressure- and trace-row right-hand side (k_condense_mfma with r_lambda)
+    rP, rL = d.pressure_reconstruction_rhs(u.reshape(-1, 2), b_new)
+    _, p, lam = d.solve_mixed_poisson(rP=rP, rL=rL)
+    p, lam = d.shift_pressure(p, lam)
+    e.pressure_solve(_lib.HDG_KEY_PRESSURE_RECONSTRUCTION)
+    e.finish_step()
+    _, gp, gl = e.get_field(_lib.HDG_STATE_CURRENT)
+    assert _relerr(gp, p) < TOL and _relerr(gl, lam) < TOL

@@ -149,3 +149,109 @@ def test_get_timesteps_and_model_problem():
     Q, p = mp.solution(0.2)
     assert np.allclose(Q.dat.data, np.exp(-0.1) * mp._Qs)
     assert TaylorGreen(VQ, Vp, "constant", 0.0).f_rhs().scale(1.0) == 0.0
+
+
+def _disassemble_device_code(tmp_path):
+    """gfx950 ISA of the built library: llvm-objdump extracts the offload bundle next to its input, so work on a copy."""
+    import shutil
+    import subprocess
+
+    from incompressibleeulerhdg_amd import _lib
+
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not found")
+    _lib.build_library()
+    so = str(tmp_path / "libhdg_mi355x.so")
+    shutil.copy(_lib.LIB_PATH, so)
+    subprocess.run([objdump, "--offloading", so], check=True, stdout=subprocess.DEVNULL, cwd=str(tmp_path))
+    co = [f for f in os.listdir(tmp_path) if "gfx950" in f]
+    assert len(co) == 1, co
+    return subprocess.run([objdump, "-d", str(tmp_path / co[0])], check=True, stdout=subprocess.PIPE).stdout.decode()
+
+
+def _vregs(tok):
+    """vector registers named by an operand token (VGPRs and AGPRs): v7 -> {("v", 7)}, a[4:7] -> {("a", 4), ...}; else {}"""
+    m = re.fullmatch(r"([va])(\d+)", tok)
+    if m:
+        return {(m.group(1), int(m.group(2)))}
+    m = re.fullmatch(r"([va])\[(\d+):(\d+)\]", tok)
+    if m:
+        return {(m.group(1), n) for n in range(int(m.group(2)), int(m.group(3)) + 1)}
+    return set()
+
+
+def _audit_16_byte_stores(asm):
+    """Checks (a) and (b) of test_isa_store_data_hazard_audit on a disassembly; returns the number of stores audited."""
+    lines = [ln.split("//")[0].strip() for ln in asm.splitlines()]
+    lines = [ln for ln in lines if ln and not ln.endswith(":") and not ln.startswith(("Disassembly", "/"))]
+    n_stores = 0
+    for idx, ln in enumerate(lines):
+        if not ln.startswith("buffer_store_dwordx4"):
+            continue
+        n_stores += 1
+        ops = [t.strip() for t in ln[len("buffer_store_dwordx4"):].split(",")]
+        # operands: vdata, vaddr, srsrc, "soffset [modifiers]"
+        assert len(ops) == 4, ln
+        soffset = ops[3].split()[0]
+        assert not soffset.startswith(("s", "m0")), f"16-byte buffer store with an SGPR soffset: {ln}"
+        data = _vregs(ops[0])
+        assert len(data) == 4, ln
+        waited, q = 0, idx + 1
+        while waited < 2 and q < len(lines):
+            nxt = lines[q]
+            mnem = nxt.split()[0]
+            if mnem.startswith(("s_endpgm", "s_branch", "s_cbranch", "s_setpc")):
+                break  # the window ends with the basic block (the audit is per fall-through path)
+            if mnem == "s_nop":
+                waited += int(nxt.split()[1], 0) + 1
+            else:
+                if mnem.startswith("v_") and not mnem.startswith("v_cmp"):
+                    dst = nxt[len(mnem):].split(",")[0].strip()
+                    assert not (_vregs(dst) & data), f"store data overwritten inside the hazard window:\n  {ln}\n  {nxt}"
+                waited += 1
+            q += 1
+    return n_stores
+
+
+def test_isa_audit_detects_the_hazard_patterns():
+    """The audit itself: the two patterns behind the round-2 defect are rejected, the padded forms are accepted."""
+    ok = """
+	buffer_store_dwordx4 v[0:3], v57, s[4:7], 0 offen          // 000: E07C1000
+	s_nop 1
+	v_fma_f64 v[0:1], v[8:9], v[8:9], 0
+	buffer_store_dwordx4 a[16:19], v10, s[56:59], 0 offen nt
+	v_add_u32_e32 v25, s1, v57
+	v_add_u32_e32 v24, s0, v24
+	v_accvgpr_write_b32 a16, v3
+"""
+    assert _audit_16_byte_stores(ok) == 2
+    with pytest.raises(AssertionError, match="SGPR soffset"):
+        _audit_16_byte_stores("	buffer_store_dwordx4 v[0:3], v57, s[4:7], s12 offen\n")
+    with pytest.raises(AssertionError, match="hazard window"):
+        _audit_16_byte_stores("	buffer_store_dwordx4 v[0:3], v57, s[4:7], 0 offen\n	v_mov_b32_e32 v2, 0\n")
+    with pytest.raises(AssertionError, match="hazard window"):
+        _audit_16_byte_stores("	buffer_store_dwordx4 a[4:7], v57, s[4:7], 0 offen\n	s_nop 0\n	v_accvgpr_write_b32 a5, v3\n")
+
+
+def test_isa_store_data_hazard_audit(tmp_path):
+    """Pins the round-2 hardware finding ('store-data hazard'): on gfx950 a 16-byte buffer store whose
+    data registers are overwritten by the next VALU instruction can pick up the new value; hipcc pads that hazard with wait
+    states only for stores WITHOUT a scalar offset register.  Audit of the shipped code object:
+      (a) no buffer_store_dwordx4 carries an SGPR soffset (VelBuf::st puts the plane offset into the vector offset);
+      (b) no VALU instruction writes a store's data registers within the 2 wait states LLVM's hazard model requires on
+          gfx940+ (VmemStoreHazard; s_nop N counts N + 1).
+    """
+    asm = _disassemble_device_code(tmp_path)
+    n_stores = _audit_16_byte_stores(asm)
+    assert n_stores > 100, n_stores  # every velocity-writing kernel stores 16-byte pairs
+
+
+def test_every_kernel_form_has_its_own_name(tmp_path):
+    """Plain / residual form of the advection operator and the lift with / without the Chebyshev epilogue are separate
+    instantiations: profiles and PMC passes tell them apart by kernel name (profiles/pmc_traffic.json is per form)."""
+    asm = _disassemble_device_code(tmp_path)
+    syms = set(re.findall(r"<(_ZN3hdg[A-Za-z0-9_]+)>:", asm))
+    for frag in ("11k_adv_applyILi2ELb1E", "11k_adv_applyILi2ELb0E", "11k_edge_liftILi2ELb0ELi2ELb1E", "11k_edge_liftILi2ELb0ELi2ELb0E",
+                 "10k_adv_mfmaILi4ELb1E", "10k_adv_mfmaILi4ELb0E"):
+        assert any(frag in sy for sy in syms), frag
