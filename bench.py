@@ -237,6 +237,39 @@ def cpu_baseline(degree, nx_sample=None):
                        f"Krylov iterations tentative/pressure {its[0]:.1f}/{its[1]:.1f} (GMRES(8) / PCG)")
 
 
+class Watchdog:
+    """Bounds every phase of a multi-rank run: `arm(what, seconds)` (re)starts a deadline, `disarm()` clears it; when a
+    deadline passes the process prints what overran and ends with exit code 4 without waiting for anybody (a rank blocked
+    inside a collective whose peer has died cannot be interrupted from Python)."""
+
+    def __init__(self, rank):
+        import threading
+
+        self.rank, self.deadline, self.what = rank, None, ""
+        self.lock = threading.Lock()
+        t = threading.Thread(target=self._run, daemon=True)
+        t.start()
+
+    def arm(self, what, seconds):
+        with self.lock:
+            self.what, self.deadline = what, time.monotonic() + seconds
+
+    def disarm(self):
+        with self.lock:
+            self.deadline = None
+
+    def _run(self):
+        while True:
+            time.sleep(1.0)
+            with self.lock:
+                late = self.deadline is not None and time.monotonic() > self.deadline
+                what = self.what
+            if late:
+                sys.stderr.write(f"bench.py [rank {self.rank}]: '{what}' overran its deadline: giving up (exit 4)\n")
+                sys.stderr.flush()
+                os._exit(4)
+
+
 def gpu_at_size(nx, k, args, kappa):
     """The GPU path on the CPU sample's mesh (same scheme, 1 warm-up + 3 timed steps), so that GPU and CPU numbers exist at
     ONE size as well as the GPU number at the headline size."""
@@ -378,15 +411,19 @@ def main():
             **({} if args.tent_solver is None else {"tent_solver": args.tent_solver}), **comm_kwargs(backend, rank, world, token))
 
     backend = args.comm if world > 1 else "none"
-    if world > 1 and backend == "rccl":
-        # rehearse the transport in a child process first: a failure or hang costs a timeout, not the run.
-        # A failure is an ERROR: a multi-GPU number over a different transport would be a different measurement
-        # (--comm shm asks for the host-staged transport explicitly).
+    # A transport that cannot initialise, or a peer that died, must cost a bounded time and a NON-ZERO exit, never a hang:
+    # a watchdog thread ends this rank (os._exit: torchrun then tears the job down) when a phase overruns its deadline.
+    # No second rendezvous, no child processes: nothing here can wedge or fail a healthy N-rank job.  (The round-2 probe --
+    # a child process per rank with its own rendezvous on another port -- remains available as an explicit self-test:
+    # BENCH_PROBE_TRANSPORT=1.)  A failure is an ERROR: a number over another transport would be another measurement.
+    watchdog = Watchdog(rank)
+    if world > 1 and backend == "rccl" and os.environ.get("BENCH_PROBE_TRANSPORT"):
         from incompressibleeulerhdg_amd.distributed import probe_transport
 
         ok_probe = probe_transport("rccl")
         if int(reduce_scalar(1.0 if ok_probe else 0.0, dist.ReduceOp.MIN)) == 0:
             raise SystemExit("bench.py: the RCCL transport probe failed on at least one rank")
+    watchdog.arm("engine construction / transport initialisation", float(os.environ.get("BENCH_INIT_TIMEOUT", "300")))
     try:
         ts = build(backend)
         ok = 1
@@ -396,6 +433,14 @@ def main():
     if int(reduce_scalar(float(ok), dist.ReduceOp.MIN)) == 0 if world > 1 else ok == 0:
         raise SystemExit(f"bench.py: engine construction failed (transport {backend})")
     eng = ts._engine
+    if world > 1:
+        crank, cn, ct, cname = eng.comm_info()
+        if (crank, cn, ct) != (rank, world, world):
+            raise SystemExit(f"bench.py: transport reports rank {crank} of {cn} ({ct} in the communicator), launch says {rank} of {world}")
+        transport_desc = f"{cname} communicator of {ct} ranks"
+    else:
+        transport_desc = "none"
+    watchdog.arm("state set-up and warm-up steps", float(os.environ.get("BENCH_STEP_TIMEOUT", "600")))
     mp = TaylorGreen(ts._V_Q, ts._V_p, "exponential", kappa)
     eng.set_state(ts._V_Q.interpolate(mp.Q_stationary), ts._V_p.interpolate(mp.p_stationary))
     eng.reconstruct_trace()
@@ -412,6 +457,7 @@ def main():
     ktiming_extra = os.environ.get("BENCH_KERNEL_TIMING", "extra") == "extra"
     eng.set_kernel_timing(not ktiming_extra)
     eng.launch_stats(reset=True)
+    watchdog.arm("timed steps", float(os.environ.get("BENCH_STEP_TIMEOUT", "600")))
     sync_barrier()
     t0 = time.perf_counter()
     eng.run_separable(ssp2_scales(args.steps, dt, kappa, t0=args.warmup * dt))  # synchronous on return
@@ -430,6 +476,7 @@ def main():
         ktimers = {lab: (n, tot) for lab, (n, tot, _) in timers_raw.items() if lab.startswith("kernel_")}
     timers_raw = {lab: v for lab, v in timers_raw.items() if not lab.startswith("kernel_")}
     eng.set_kernel_timing(False)
+    watchdog.disarm()
 
     if rank == 0:
         its = {n: (float(s / c) if c else 0.0) for n, s, c in zip(
@@ -461,7 +508,7 @@ def main():
                                    f"Taylor-Green kappa=0.5, dt=0.25/nx (BASELINE C3)" if (nx, k) == (1024, 2)
                        else f"HDG-IMEX SSP2(3,3,2) R=2 projection upwind, k={k}, {nx}x{nx} tri mesh",
                        "n_dof": ntot, "krylov_iterations_avg": its,
-                       "parallelism": f"strip partition over {world} rank(s), transport {backend}"
+                       "parallelism": f"strip partition over {world} rank(s), transport {transport_desc}"
                                       + (" (ranks share GPUs: rehearsal)" if shared_gpu else "")},
             "roofline": roof,
             "timers": timers,

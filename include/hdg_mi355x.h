@@ -186,6 +186,10 @@ int hdg_set_kernel_timing(hdg_handle* h, int on);
  * 3 weak_divergence, 4 condense (K5), 5 trace_apply (K6), 6 trace_smooth (K7: smoother steps on the trace space),
  * 7 backsub (K8), 8 vertex_multigrid (K7: P1 V-cycle and transfers), 9 vector_update (K9), 10 dot (K9),
  * 11 copy_fill, 12 other (scalar kernels, trace reconstruction, constraint rows). */
+/* Transport of a distributed handle as the transport itself reports it: this rank, the number of ranks of the strip
+ * partition, the size of the communicator (RCCL: ncclCommCount; must equal nranks) and its name ("self", "rccl", "shm";
+ * name16: at least 16 bytes).  No reference counterpart (the reference has no explicit communication). */
+int hdg_get_comm_info(const hdg_handle* h, int* rank, int* nranks, int* transport_ranks, char* name16);
 #define HDG_N_LAUNCH_CLASSES 13
 int hdg_get_launch_stats(hdg_handle* h, long* calls, double* bytes, int reset);
 

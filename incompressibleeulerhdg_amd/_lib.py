@@ -123,6 +123,7 @@ SIGNATURES = {
     "hdg_get_timers": [_h, _dp, _dp, _lp, C.c_int],
     "hdg_set_kernel_timing": [_h, C.c_int],
     "hdg_get_launch_stats": [_h, _lp, _dp, C.c_int],
+    "hdg_get_comm_info": [_h, _ip, _ip, _ip, C.c_char_p],
     "hdg_set_tracer": [_h, _dp],
     "hdg_get_tracer": [_h, _dp],
     "hdg_tracer_begin_step": [_h],
@@ -430,6 +431,13 @@ class Engine:
         nbytes = np.zeros(n)
         self._ck(self.lib.hdg_get_launch_stats(self.h, calls.ctypes.data_as(_lp), _ptr(nbytes), 1 if reset else 0))
         return {lab: (int(c), float(b)) for lab, c, b in zip(self.LAUNCH_CLASSES, calls, nbytes)}
+
+    def comm_info(self):
+        """(rank, ranks of the partition, ranks the transport reports, transport name) -- hdg_get_comm_info"""
+        r, n, t = C.c_int(), C.c_int(), C.c_int()
+        name = C.create_string_buffer(16)
+        self._ck(self.lib.hdg_get_comm_info(self.h, C.byref(r), C.byref(n), C.byref(t), name))
+        return r.value, n.value, t.value, name.value.decode()
 
     def set_kernel_timing(self, on):
         self._ck(self.lib.hdg_set_kernel_timing(self.h, 1 if on else 0))

@@ -49,6 +49,10 @@ struct Comm {
     if (send != recv) (void)hipMemcpyAsync(recv, send, n * sizeof(double), hipMemcpyDeviceToDevice, st);
   }
   virtual const char* name() const { return "self"; }
+  // number of ranks the transport itself reports (RCCL: ncclCommCount), for the bench line
+  virtual int transport_size() const { return size; }
+  // deferred errors of earlier asynchronous operations (RCCL: ncclCommGetAsyncError); throws CommError
+  virtual void check_async() {}
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -61,6 +65,28 @@ struct CommRccl : Comm {
     std::memcpy(&id, id128, sizeof(id));
     ncclResult_t r = ncclCommInitRank(&comm, size, id, rank);
     if (r != ncclSuccess) throw CommError{std::string("ncclCommInitRank: ") + ncclGetErrorString(r)};
+    // the communicator must be the one this rank believes it is part of: a mismatch (stale token, wrong WORLD_SIZE) would
+    // otherwise surface as a hang in the first send / recv
+    int cnt = -1, me = -1;
+    if (ncclCommCount(comm, &cnt) != ncclSuccess || ncclCommUserRank(comm, &me) != ncclSuccess || cnt != size || me != rank) {
+      ncclCommAbort(comm);
+      comm = nullptr;
+      throw CommError{"RCCL communicator does not match the launch: size " + std::to_string(cnt) + " (expected " +
+                      std::to_string(size) + "), rank " + std::to_string(me) + " (expected " + std::to_string(rank) + ")"};
+    }
+  }
+  int transport_size() const override {
+    int cnt = -1;
+    return (comm && ncclCommCount(comm, &cnt) == ncclSuccess) ? cnt : -1;
+  }
+  void check_async() override {
+    if (!comm) return;
+    ncclResult_t st = ncclSuccess;
+    ncclResult_t r = ncclCommGetAsyncError(comm, &st);
+    if (r != ncclSuccess || (st != ncclSuccess && st != ncclInProgress)) {
+      failed = true;
+      throw CommError{std::string("RCCL asynchronous error: ") + ncclGetErrorString(r != ncclSuccess ? r : st)};
+    }
   }
   ~CommRccl() override {
     // after a rank-local failure the peers may be blocked inside a collective: abort (does not wait for them)

@@ -270,6 +270,9 @@ struct Engine {
     tm_open.clear();
     for (hipEvent_t e : tm_pool) (void)hipEventDestroy(e);
     tm_pool.clear();
+    if (ev_in) { (void)hipEventDestroy(ev_in); ev_in = nullptr; }
+    if (ev_halo) { (void)hipEventDestroy(ev_halo); ev_halo = nullptr; }
+    if (cstream) { (void)hipStreamDestroy(cstream); cstream = nullptr; }
     if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; }
     delete tab;
     tab = nullptr;
@@ -285,6 +288,7 @@ struct Engine {
     g.nyc = g.ny + (comm->rank == comm->size - 1 ? 1 : 0);
     periodic = c.periodic != 0;
     Ldom = c.length > 0 ? c.length : 1.0;
+    overlap_on = !std::getenv("HDG_NO_OVERLAP") && (std::strcmp(comm->name(), "rccl") == 0 || std::getenv("HDG_OVERLAP") != nullptr);
     if (periodic && comm->size > 1) throw std::string("the periodic mesh is implemented for a single rank");
     if (periodic && (c.nx % 2 != 0)) throw std::string("the periodic mesh needs an even nx (red-black coarse-grid sweeps)");
     if (periodic && g.ny < GH) throw std::string("the periodic mesh needs at least 4 cell rows");
@@ -315,10 +319,12 @@ struct Engine {
     g.nbxc = (g.nx + 1 + bs() - 1) / bs();
     g.rows_xcd = (g.ny + 7) / 8;
     g.rows_xcdc = (g.nyc + 7) / 8;
+    g.wskip = 0; g.wgap0 = 0; g.wgapn = 0; g.wrows = g.ny; g.wrowsc = g.nyc;
     g.dbg_nonbr = std::getenv("HDG_DBG_NONBR") ? 1 : 0;
     g_all = g;
     g_all.nyc = g.ny + (periodic ? 0 : 1);
     g_all.rows_xcdc = (g_all.nyc + 7) / 8;
+    g_all.wrowsc = g_all.nyc;
     NQ = 2L * NU * g.Nc; NPv = (long)NP * g.Nc; NLv = 3L * NL * g.G;
     // cell kernels address a vector with 32-bit byte offsets (buffer loads, hdg_kernels.hpp: CellBuf)
     if (NQ * 8L >= (1L << 32))
@@ -335,8 +341,8 @@ struct Engine {
   }
   ~Engine() {
     if (debug_on() && comm && comm->rank == 0)
-      fprintf(stderr, "[comm] halo exchanges: velocity %ld, pressure %ld, trace %ld, vertex rows %ld; all-reduces %ld; all-gathers %ld\n",
-              n_halo[0], n_halo[1], n_halo[2], n_halo_mg, n_reduce, n_gather);
+      fprintf(stderr, "[comm] halo exchanges: velocity %ld, pressure %ld, trace %ld, vertex rows %ld (%ld of them beside an interior launch); all-reduces %ld; all-gathers %ld\n",
+              n_halo[0], n_halo[1], n_halo[2], n_halo_mg, n_overlapped, n_reduce, n_gather);
     if (flow_check && comm && comm->rank == 0)
       fprintf(stderr, "[flow check] %ld skipped exchanges verified, worst relative deviation %.3e\n", fc_count, fc_worst);
     release();
@@ -534,6 +540,8 @@ struct Engine {
   // Redundant work: 6 row launches of operator + lift per two velocity iterations and side, 18 per CG iteration.
   // Strips of 2-3 rows use Dx = ny; Dx = 1 (HDG_NO_EXT, periodic wrap, outside a FlowScope) is the classic exchange
   // before every stencil.  A vector the bookkeeping has not seen counts as 0: the default is always the safe one.
+  // an exchange stencil_in() has decided on but left to its caller (stencil_launch: beside the interior launch)
+  struct Pending { bool on = false; const double* v = nullptr; int kind = 0, depth = 0; };
   struct Flow {
     int nest = 0, Dx = 1;
     std::vector<std::pair<const double*, int>> v;
@@ -566,10 +574,15 @@ struct Engine {
   };
   enum { FQ = 0, FP = 1, FL = 2 };
   // input of a row stencil: at least one valid ghost row; returns the number of ghost rows the stencil may compute
-  int stencil_in(const double* in, int kind) {
+  int stencil_in(const double* in, int kind, Pending* defer = nullptr) {
     const int depth = fl.active() ? fl.Dx : 1;
     if (!fl.active() || fl.get(in) < 1) {
-      if (kind == FQ) halo_Q(in, depth); else if (kind == FP) halo_P(in); else halo_L(in, depth);
+      const bool real_exchange = comm->size > 1 && halo_on && !periodic;
+      if (defer && real_exchange && overlap_on && kind != FP) {
+        defer->on = true; defer->v = in; defer->kind = kind; defer->depth = depth;  // the caller runs it (halo_run)
+      } else {
+        if (kind == FQ) halo_Q(in, depth); else if (kind == FP) halo_P(in); else halo_L(in, depth);
+      }
       fl.set(in, kind == FP ? 1 : depth);
     } else if (flow_check) {
       flow_check_input(in, kind, fl.get(in));  // no exchange needed, says the bookkeeping: verify
@@ -589,8 +602,100 @@ struct Engine {
       c.ehi = comm->rank < comm->size - 1 ? ext : 0;
       c.rows_xcd = (c.ny + c.elo + c.ehi + 7) / 8;
       c.rows_xcdc = (c.nyc + c.elo + c.ehi + 7) / 8;
+      c.wrows = c.ny + c.elo + c.ehi;
+      c.wrowsc = c.nyc + c.elo + c.ehi;
     }
     return c;
+  }
+  // ---- interior / boundary split of a stencil launch whose input is being exchanged (strip partition, SURVEY.md 5.8:
+  // "interior elements computed while cut-edge data is in flight").  Rows whose stencil reads owned rows of the input only:
+  // cells j in [lo, ny - hi), corners j in [lo, nyc - hi) with lo / hi = 1 where a neighbour exists.  The interior launch
+  // runs on the compute stream while pack -> send/recv -> unpack run on the communication stream; the boundary launch
+  // (ghost rows and the first / last owned row, ONE launch with a gap over the interior) waits for the unpack.
+  bool can_split(const Geo& full) const {
+    const int lo = comm->rank > 0 ? 1 : 0, hi = comm->rank < comm->size - 1 ? 1 : 0;
+    return overlap_on && comm->size > 1 && full.ny - lo - hi >= 2 && (full.elo + lo + full.ehi + hi) > 0;
+  }
+  Geo window_interior(const Geo& full) const {
+    Geo c = full;
+    const int lo = comm->rank > 0 ? 1 : 0, hi = comm->rank < comm->size - 1 ? 1 : 0;
+    c.wskip = full.elo + lo; c.wgap0 = 0; c.wgapn = 0;
+    c.wrows = full.ny - lo - hi;
+    c.wrowsc = full.nyc - lo - hi;
+    c.rows_xcd = (c.wrows + 7) / 8;
+    c.rows_xcdc = (c.wrowsc + 7) / 8;
+    return c;
+  }
+  Geo window_boundary(const Geo& full) const {
+    Geo c = full;
+    const int lo = comm->rank > 0 ? 1 : 0, hi = comm->rank < comm->size - 1 ? 1 : 0;
+    c.wskip = 0;
+    c.wgap0 = full.elo + lo;                    // the rows below the interior ...
+    c.wgapn = full.ny - lo - hi;                // ... then skip it (cells)
+    c.wrows = full.elo + lo + hi + full.ehi;
+    c.wrowsc = c.wrows;                         // corners: the gap is nyc - lo - hi rows long (set by the corner launches)
+    c.rows_xcd = (c.wrows + 7) / 8;
+    c.rows_xcdc = (c.wrowsc + 7) / 8;
+    return c;
+  }
+  static Geo corner_gap(Geo c, const Geo& full, int lo, int hi) { c.wgapn = full.nyc - lo - hi; return c; }
+  hipStream_t cstream = nullptr;               // communication stream (exchanges that overlap with interior launches)
+  hipEvent_t ev_in = nullptr, ev_halo = nullptr;
+  // On by default over RCCL (device-side send / recv: nothing blocks the host).  Off by default over the host-staged
+  // shared-memory transport: that one exists for ranks SHARING a device, where the interior launch occupies the very GPU the
+  // peer needs for its pack kernel (C3 rehearsal, 2 ranks on one MI355X: 226 ms/step with the split, 178 without).
+  // HDG_OVERLAP=1 forces it on (the multi-rank tests, which run over shared memory), HDG_NO_OVERLAP=1 off.
+  bool overlap_on = false;
+  long n_overlapped = 0;                        // exchanges that ran beside an interior launch (census)
+  // the deferred exchange of stencil_in(): runs on the communication stream after everything queued on the compute stream
+  // so far (the producer of v); the compute stream continues and waits in halo_finish()
+  void halo_run(const Pending& pd) {
+    if (!pd.on) return;
+    if (!cstream) {
+      HIPCHECK(hipStreamCreateWithFlags(&cstream, hipStreamNonBlocking));
+      HIPCHECK(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
+      HIPCHECK(hipEventCreateWithFlags(&ev_halo, hipEventDisableTiming));
+    }
+    HIPCHECK(hipStreamWaitEvent(cstream, ev_in, 0));
+    hipStream_t saved = stream;
+    stream = cstream;  // halo_rows packs / exchanges / unpacks on `stream`
+    try {
+      if (pd.kind == FQ) halo_Q(pd.v, pd.depth); else halo_L(pd.v, pd.depth);
+    } catch (...) { stream = saved; throw; }
+    stream = saved;
+    HIPCHECK(hipEventRecord(ev_halo, cstream));
+    HIPCHECK(hipStreamWaitEvent(stream, ev_halo, 0));
+    n_overlapped++;
+  }
+  void halo_mark(const Pending& pd) {  // the producer of pd.v has been queued: everything before this point
+    if (!pd.on) return;
+    if (!cstream) {
+      HIPCHECK(hipStreamCreateWithFlags(&cstream, hipStreamNonBlocking));
+      HIPCHECK(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
+      HIPCHECK(hipEventCreateWithFlags(&ev_halo, hipEventDisableTiming));
+    }
+    HIPCHECK(hipEventRecord(ev_in, stream));
+  }
+  // a stencil launch with its input exchange overlapped: launch(const Geo&) is called once (no exchange needed, or no split)
+  // or twice (interior, then boundary after the exchange)
+  template <class L>
+  void stencil_launch(const double* in, int kind, int max_ext, bool corner, const std::vector<const double*>& pw, L&& launch,
+                      int* ext_out) {
+    Pending pd;
+    int ext = std::min(stencil_in(in, kind, &pd), max_ext);
+    for (const double* q : pw) ext = pw_in(q, ext);
+    const Geo full = g_ext(ext);
+    if (ext_out) *ext_out = ext;
+    if (pd.on && can_split(full)) {
+      const int lo = comm->rank > 0 ? 1 : 0, hi = comm->rank < comm->size - 1 ? 1 : 0;
+      halo_mark(pd);
+      launch(window_interior(full));
+      halo_run(pd);
+      launch(corner ? corner_gap(window_boundary(full), full, lo, hi) : window_boundary(full));
+    } else {
+      if (pd.on) { halo_mark(pd); halo_run(pd); }
+      launch(full);
+    }
   }
   dim3 cell_grid_of(const Geo& c) const { return dim3(8 * c.rows_xcd * 2 * c.nbx, 1, 1); }
   static dim3 corner_grid_of(const Geo& c) { return dim3(8 * c.rows_xcdc * c.nbxc, 1, 1); }
@@ -856,21 +961,24 @@ struct Engine {
   // optionally fused with the Chebyshev step; G0 / G1: tables (I - Dinv_s) Lift_e of the stage (ensure_dinv)
   void bdm_hybrid(const double* in, double* out, const double* D0, const double* D1, double* chd_ = nullptr,
                   double* chx_ = nullptr, double c1 = 0.0, double c2 = 0.0, double* ss = nullptr) {
-    const int ext = lift_ext(in, nullptr, chd_, chx_, c1);
-    const Geo gx = g_ext(ext);
-    fl.set(out, ext); fl.set(chd_, ext);
     // Chebyshev mode: the lift of an iteration carries the fused step (per-thread kernel) or is the matrix-core kernel
     // followed by the vector-kernel step; GMRES mode: the plain lift
     KTimed kt_(*this, T_KLIFT, fl.active() && (cfg.tent_solver == 1 ? (chd_ != nullptr || (use_mfma_lift() && out && !ss))
                                                                       : chd_ == nullptr));
     tally(LC_LIFT, lift_bytes(false, out != nullptr, chd_ != nullptr, c1));
-    if (use_mfma_lift() && out && !chd_ && !ss) {
-      // GMRES path at k >= 3: no Chebyshev epilogue -> matrix-core kernel with the packed G tables of this stage
-      for (size_t q = 0; q < hybg0.size(); q++)
-        if (hybg0[q] == D0) { lift_mfma(gx, liftm_hyb0[q], liftm_hyb1[q], in, out); return; }
-    }
-    if (chd_) { HDG_DISPATCH(k_edge_lift<KK, false, 2, true><<<cell_grid_of(gx), bs(), 0, stream>>>(gx, dt, in, out, nullptr, D0, D1, chd_, chx_, c1, c2, ss)); }
-    else { HDG_DISPATCH(k_edge_lift<KK, false, 2, false><<<cell_grid_of(gx), bs(), 0, stream>>>(gx, dt, in, out, nullptr, D0, D1, chd_, chx_, c1, c2, ss)); }
+    std::vector<const double*> pw;
+    if (chd_) { pw.push_back(chx_); if (c1 != 0.0) pw.push_back(chd_); }
+    int ext = 0;
+    stencil_launch(in, FQ, GH, false, pw, [&](const Geo& gx) {
+      if (use_mfma_lift() && out && !chd_ && !ss) {
+        // GMRES path at k >= 3: no Chebyshev epilogue -> matrix-core kernel with the packed G tables of this stage
+        for (size_t q = 0; q < hybg0.size(); q++)
+          if (hybg0[q] == D0) { lift_mfma(gx, liftm_hyb0[q], liftm_hyb1[q], in, out); return; }
+      }
+      if (chd_) { HDG_DISPATCH(k_edge_lift<KK, false, 2, true><<<cell_grid_of(gx), bs(), 0, stream>>>(gx, dt, in, out, nullptr, D0, D1, chd_, chx_, c1, c2, ss)); }
+      else { HDG_DISPATCH(k_edge_lift<KK, false, 2, false><<<cell_grid_of(gx), bs(), 0, stream>>>(gx, dt, in, out, nullptr, D0, D1, chd_, chx_, c1, c2, ss)); }
+    }, &ext);
+    fl.set(out, ext); fl.set(chd_, ext);
   }
   void bdm_T(const double* in, double* out) {
     const int ext = stencil_in(in, FQ);
@@ -880,46 +988,48 @@ struct Engine {
     fl.set(out, ext);
   }
   void adv_apply(const double* x, const double* qstar, double* out, double gamma, const double* bsub = nullptr) {
-    const int ext = pw_in(bsub, pw_in(qstar, stencil_in(x, FQ)));
-    const Geo g = g_ext(ext);  // this launch's copy (row extension); shadows the member on purpose
-    fl.set(out, ext);
-    const dim3 cgrid = cell_grid_of(g);
     KTimed kt_(*this, T_KADV, fl.active() && ((cfg.tent_solver == 1) == (bsub != nullptr)));
     const double up = cfg.flux_upwind ? 1.0 : 0.0;
     tally(LC_ADV, bQ() * (bsub ? 4 : 3));
     // k >= 3: the whole operator on the matrix cores (k_adv_mfma); HDG_NO_MFMA_ADV falls back to the per-thread kernels
     static const bool no_mfma_adv = std::getenv("HDG_NO_MFMA_ADV") != nullptr;
-    if (!no_mfma_adv && cfg.degree >= mfma_min_degree() && !periodic) {
-      if (!advm[0]) {
-        if (dt.nqc != (cfg.degree == 2 ? 16 : (cfg.degree == 3 ? 36 : 64))) throw std::string("cell quadrature size does not match the matrix-core advection kernel");
-        for (int sh = 0; sh < 2; sh++) advm[sh] = upload(pack_adv_mfma(sh));
-      }
-      const dim3 gridc(8 * g.rows_xcd * 2);
+    const bool mfma = !no_mfma_adv && cfg.degree >= mfma_min_degree() && !periodic;
+    if (mfma && !advm[0]) {
+      if (dt.nqc != (cfg.degree == 2 ? 16 : (cfg.degree == 3 ? 36 : 64))) throw std::string("cell quadrature size does not match the matrix-core advection kernel");
       if (dt.nqe != (3 * cfg.degree + 5) / 2) throw std::string("edge quadrature size does not match the matrix-core advection kernel");
-      auto launch = [&](auto kk, auto res) {
-        constexpr int KK = decltype(kk)::value;
-        constexpr bool RS = decltype(res)::value;
-        k_adv_mfma<KK, RS><<<gridc, 512, 0, stream>>>(g, dt, advm[0], advm[1], x, qstar, out, gamma, up, bsub);
-      };
-      auto by_form = [&](auto kk) { if (bsub) launch(kk, std::true_type{}); else launch(kk, std::false_type{}); };
-      if (cfg.degree == 2) by_form(std::integral_constant<int, 2>{});
-      else if (cfg.degree == 3) by_form(std::integral_constant<int, 3>{});
-      else by_form(std::integral_constant<int, 4>{});
-      return;
+      for (int sh = 0; sh < 2; sh++) advm[sh] = upload(pack_adv_mfma(sh));
     }
-    // k = 3: two lanes per cell, one velocity component each (k_adv_apply2).  Measured at nx = 512, one-lane vs
-    // two-lane kernel: k=1 181 / 205 us (nx 1024), k=2 353 / 370 us (nx 1024), k=3 407 / 334 us, k=4 719 / 1488 us
-    // (254 VGPRs, still 1 wave/SIMD, twice the waves).  HDG_ADV_SPLIT=lo:hi overrides the degree range.
+    // k = 3 without the matrix-core kernel: two lanes per cell, one velocity component each (k_adv_apply2).  Measured at
+    // nx = 512, one-lane vs two-lane kernel: k=1 181 / 205 us (nx 1024), k=2 353 / 370 us (nx 1024), k=3 407 / 334 us,
+    // k=4 719 / 1488 us (254 VGPRs, still 1 wave/SIMD, twice the waves).  HDG_ADV_SPLIT=lo:hi overrides the degree range.
     static const char* split_env = std::getenv("HDG_ADV_SPLIT");
     int split_lo = 3, split_hi = 3;
     if (split_env) std::sscanf(split_env, "%d:%d", &split_lo, &split_hi);
-    if (cfg.degree >= split_lo && cfg.degree <= split_hi) {
-      const int cpb = bs() / 2, nbx2 = (g.nx + cpb - 1) / cpb;
-      HDG_DISPATCH(k_adv_apply2<KK><<<dim3(8 * g.rows_xcd * 2 * nbx2), bs(), 0, stream>>>(g, dt, x, qstar, out, gamma, up, bsub));
-      return;
-    }
-    if (bsub) { HDG_DISPATCH(k_adv_apply<KK, true><<<cgrid, bs(), 0, stream>>>(g, dt, x, qstar, out, gamma, up, bsub)); }
-    else { HDG_DISPATCH(k_adv_apply<KK, false><<<cgrid, bs(), 0, stream>>>(g, dt, x, qstar, out, gamma, up, bsub)); }
+    const bool two_lane = cfg.degree >= split_lo && cfg.degree <= split_hi;
+    int ext = 0;
+    // the launch of one row window (the whole extended strip, or interior / boundary rows around the exchange of x)
+    stencil_launch(x, FQ, GH, false, {qstar, bsub}, [&](const Geo& g) {  // shadows the member on purpose
+      if (mfma) {
+        const dim3 gridc(8 * g.rows_xcd * 2);
+        auto launch = [&](auto kk, auto res) {
+          constexpr int KK = decltype(kk)::value;
+          constexpr bool RS = decltype(res)::value;
+          k_adv_mfma<KK, RS><<<gridc, 512, 0, stream>>>(g, dt, advm[0], advm[1], x, qstar, out, gamma, up, bsub);
+        };
+        auto by_form = [&](auto kk) { if (bsub) launch(kk, std::true_type{}); else launch(kk, std::false_type{}); };
+        if (cfg.degree == 2) by_form(std::integral_constant<int, 2>{});
+        else if (cfg.degree == 3) by_form(std::integral_constant<int, 3>{});
+        else by_form(std::integral_constant<int, 4>{});
+      } else if (two_lane) {
+        const int cpb = bs() / 2, nbx2 = (g.nx + cpb - 1) / cpb;
+        HDG_DISPATCH(k_adv_apply2<KK><<<dim3(8 * g.rows_xcd * 2 * nbx2), bs(), 0, stream>>>(g, dt, x, qstar, out, gamma, up, bsub));
+      } else if (bsub) {
+        HDG_DISPATCH(k_adv_apply<KK, true><<<cell_grid_of(g), bs(), 0, stream>>>(g, dt, x, qstar, out, gamma, up, bsub));
+      } else {
+        HDG_DISPATCH(k_adv_apply<KK, false><<<cell_grid_of(g), bs(), 0, stream>>>(g, dt, x, qstar, out, gamma, up, bsub));
+      }
+    }, &ext);
+    fl.set(out, ext);
   }
   void blockdiag(const double* D0, const double* D1, const double* r, const double* zin, double cz, double* out) {
     tally(LC_LIFT, bQ() * (zin ? 3 : 2));
@@ -961,23 +1071,27 @@ struct Engine {
     else { HDG_DISPATCH(k_weak_div<KK, false><<<cell_grid(), bs(), 0, stream>>>(g, dt, q, sc, out)); }
   }
   void trace_apply(const double* lam, const double* base, double cb, double ct, double* out, int max_ext = GH) {
-    int ext = std::min(stencil_in(lam, FL), max_ext);
-    if (cb != 0.0) ext = pw_in(base, ext);
-    const Geo c = g_ext(ext);
     tally(LC_TRACE_APPLY, bL() * (2 + ((base && cb != 0.0) ? 1 : 0)));
-    HDG_DISPATCH(k_trace_apply<KK><<<corner_grid_of(c), bs(), 0, stream>>>(c, pdt(), lam, base, cb, ct, out));
+    std::vector<const double*> pw;
+    if (cb != 0.0) pw.push_back(base);
+    int ext = 0;
+    stencil_launch(lam, FL, max_ext, true, pw, [&](const Geo& c) {
+      HDG_DISPATCH(k_trace_apply<KK><<<corner_grid_of(c), bs(), 0, stream>>>(c, pdt(), lam, base, cb, ct, out));
+    }, &ext);
     fl.set(out, ext);
   }
   // fused smoother step (k_trace_smooth): r = cb*base + ct*(-S) v, z = Dinv r, dn = c1 v + c2 z, optional outputs
   void trace_smooth(const double* v, const double* base, double cb, double ct, double c1, double c2, double* r_out,
                     double* d_out, double* x, bool xadd, double xv) {
-    int ext = stencil_in(v, FL);
-    if (cb != 0.0) ext = pw_in(base, ext);
-    if (x && xadd) ext = pw_in(x, ext);
-    const Geo c = g_ext(ext);
     tally(LC_TRACE_SMOOTH, bL() * (1 + (base ? 1 : 0) + (r_out ? 1 : 0) + (d_out ? 1 : 0) + (x ? (xadd ? 2 : 1) : 0)));
-    HDG_DISPATCH(k_trace_smooth<KK><<<corner_grid_of(c), bs(), 0, stream>>>(c, pdt(), v, base, cb, ct, c1, c2, r_out, d_out, x,
-                                                                         xadd ? 1 : 0, xv));
+    std::vector<const double*> pw;
+    if (cb != 0.0) pw.push_back(base);
+    if (x && xadd) pw.push_back(x);
+    int ext = 0;
+    stencil_launch(v, FL, GH, true, pw, [&](const Geo& c) {
+      HDG_DISPATCH(k_trace_smooth<KK><<<corner_grid_of(c), bs(), 0, stream>>>(c, pdt(), v, base, cb, ct, c1, c2, r_out, d_out, x,
+                                                                           xadd ? 1 : 0, xv));
+    }, &ext);
     fl.set(r_out, ext); fl.set(d_out, ext); fl.set(x, ext);
   }
   void trace_cheb(const double* r, double* d, double* x, double c1, double c2, bool assign = false) {
@@ -2823,14 +2937,15 @@ static std::string g_create_error;
   try {
 #define HDG_API_END(h)                                                        \
     hipError_t _le = hipStreamSynchronize(E.stream);                          \
-    if (_le != hipSuccess) { (h)->err = std::string("HIP: ") + hipGetErrorString(_le); return HDG_ERR_HIP; } \
+    if (_le != hipSuccess) { (h)->err = std::string("HIP: ") + hipGetErrorString(_le); if (E.comm) E.comm->failed = true; return HDG_ERR_HIP; } \
+    if (E.comm) E.comm->check_async();  /* a failed collective must not pass as a finished call */ \
     _le = hipGetLastError();                                                  \
     if (_le != hipSuccess) { (h)->err = std::string("HIP launch: ") + hipGetErrorString(_le); return HDG_ERR_HIP; } \
     E.harvest_timers();                                                       \
     return HDG_OK;                                                            \
   } catch (const hdg::HipError& e) { (h)->err = e.msg; if (E.comm) E.comm->failed = true; return HDG_ERR_HIP; \
   } catch (const hdg::NotConverged& e) { (h)->err = e.msg; return HDG_ERR_NOT_CONVERGED; \
-  } catch (const hdg::CommError& e) { (h)->err = e.msg; return HDG_ERR_COMM;       \
+  } catch (const hdg::CommError& e) { (h)->err = e.msg; if (E.comm) E.comm->failed = true; return HDG_ERR_COMM; \
   } catch (const std::string& e) { (h)->err = e; return HDG_ERR_ARG;          \
   } catch (const std::exception& e) { (h)->err = e.what(); return HDG_ERR_ARG; \
   } catch (...) { (h)->err = "unknown error"; return HDG_ERR_ARG; }
@@ -3092,6 +3207,15 @@ int hdg_get_timers(hdg_handle* h, double* total_ms, double* sumsq_ms, long* ncal
     if (reset) { E.tm_total[i] = 0; E.tm_sumsq[i] = 0; E.tm_calls[i] = 0; }
   }
   HDG_API_END(h)
+}
+int hdg_get_comm_info(const hdg_handle* h, int* rank, int* nranks, int* transport_ranks, char* name16) {
+  if (!h || !h->eng || !h->eng->comm) return HDG_ERR_ARG;
+  const hdg::Comm& c = *h->eng->comm;
+  if (rank) *rank = c.rank;
+  if (nranks) *nranks = c.size;
+  if (transport_ranks) *transport_ranks = c.transport_size();
+  if (name16) { std::strncpy(name16, c.name(), 15); name16[15] = 0; }
+  return HDG_OK;
 }
 int hdg_get_launch_stats(hdg_handle* h, long* calls, double* bytes, int reset) {
   if (!h || !h->eng) return HDG_ERR_ARG;

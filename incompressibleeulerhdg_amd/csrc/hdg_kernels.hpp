@@ -60,7 +60,13 @@ struct Geo {
   // THIS launch also computes elo ghost rows below and ehi above the owned rows (at most GH - 1; rows_xcd / rows_xcdc
   // of the copy cover the extended range): the stencil operators of the two solvers (Engine::Flow).
   int elo, ehi;
+  // Row WINDOW of this launch (round 3: interior / boundary split, Engine::halo_overlap): the launch visits wrows cell rows
+  // (wrowsc corner rows), r = 0 .. wrows-1  ->  j = r - elo + wskip, and rows r >= wgap0 are shifted by a further wgapn.
+  // Default (the whole extended strip): wskip = 0, wgapn = 0, wrows = ny + elo + ehi, wrowsc = nyc + elo + ehi.
+  // Interior launch: the rows whose stencil reads owned rows only; boundary launch: the rest, the gap spans the interior.
+  int wskip, wgap0, wgapn, wrows, wrowsc;
 };
+__device__ __forceinline__ int launch_row(const Geo& g, int r) { return r - g.elo + g.wskip + ((g.wgapn && r >= g.wgap0) ? g.wgapn : 0); }
 constexpr int GH = 4;  // ghost rows on either side of the strip in every cell / pressure / trace array
 __device__ __forceinline__ long rowbase(const Geo& g, int s, int j) { return ((long)s * g.R + (j + GH)) * g.nx; }
 __device__ __forceinline__ int xm1(const Geo& g, int i) { return i > 0 ? i - 1 : g.nx - 1; }       // column to the left
@@ -93,8 +99,9 @@ struct DevTables {
   const int jj_ = q_ / (2 * g.nbx), rem_ = q_ - jj_ * 2 * g.nbx;   \
   const int s = rem_ / g.nbx;                                      \
   const int i = (rem_ - s * g.nbx) * blockDim.x + threadIdx.x;     \
-  const int j = xcd_ * g.rows_xcd + jj_ - g.elo;                   \
-  if (jj_ >= g.rows_xcd || j >= g.ny + g.ehi || i >= g.nx) return; \
+  const int r_ = xcd_ * g.rows_xcd + jj_;                          \
+  const int j = launch_row(g, r_);                                 \
+  if (jj_ >= g.rows_xcd || r_ >= g.wrows || i >= g.nx) return;     \
   const long c = rowbase(g, s, j) + i;
 
 __device__ __forceinline__ bool nbr(int s, int e, int i, int j, const Geo& g, long& cn) {
@@ -437,8 +444,9 @@ __global__ __launch_bounds__(64 * HDG_LIFT_MFMA_WAVES) void k_edge_lift_mfma(Geo
   // (xcd band, row, shape) of this workgroup
   const int xcd_ = blockIdx.x & 7, q_ = blockIdx.x >> 3;
   const int jj_ = q_ >> 1, s = q_ & 1;
-  const int j = xcd_ * g.rows_xcd + jj_ - g.elo;
-  if (jj_ >= g.rows_xcd || j >= g.ny + g.ehi) return;  // whole workgroup
+  const int r_ = xcd_ * g.rows_xcd + jj_;
+  const int j = launch_row(g, r_);
+  if (jj_ >= g.rows_xcd || r_ >= g.wrows) return;  // whole workgroup
   const double* __restrict__ tsrc = s == 0 ? tabs0 : tabs1;
   for (int p = threadIdx.x; p < L::NTILES * 64; p += 64 * HDG_LIFT_MFMA_WAVES) tab[p] = tsrc[p];
   __syncthreads();
@@ -699,8 +707,9 @@ __global__ __launch_bounds__(128) void k_adv_apply2(Geo g, DevTables T, const do
   const int s = rem_ / nbx2;
   const int i = (rem_ - s * nbx2) * cpb + (threadIdx.x >> 1);
   const int a = threadIdx.x & 1;  // velocity component of this lane
-  const int j = xcd_ * g.rows_xcd + jj_ - g.elo;
-  if (jj_ >= g.rows_xcd || j >= g.ny + g.ehi || i >= g.nx) return;  // both lanes of a pair leave together
+  const int r_ = xcd_ * g.rows_xcd + jj_;
+  const int j = launch_row(g, r_);
+  if (jj_ >= g.rows_xcd || r_ >= g.wrows || i >= g.nx) return;  // both lanes of a pair leave together
   const long c = rowbase(g, s, j) + i;
   // lane parity = component = the slot inside a mode's 16-byte pair: a lane pair reads one pair per mode
   const long cbase = (c << 1) + a;
@@ -822,8 +831,9 @@ __global__ __launch_bounds__(512) void k_adv_mfma(Geo g, DevTables T, const doub
   __shared__ double slab[8][2][24][16];
   const int xcd_ = blockIdx.x & 7, q_ = blockIdx.x >> 3;
   const int jj_ = q_ >> 1, s = q_ & 1;
-  const int j = xcd_ * g.rows_xcd + jj_ - g.elo;
-  if (jj_ >= g.rows_xcd || j >= g.ny + g.ehi) return;  // whole workgroup
+  const int r_ = xcd_ * g.rows_xcd + jj_;
+  const int j = launch_row(g, r_);
+  if (jj_ >= g.rows_xcd || r_ >= g.wrows) return;  // whole workgroup
   const double* __restrict__ tsrc = s == 0 ? tabs0 : tabs1;
   for (int p = threadIdx.x; p < A::NTILES * 64; p += 512) tab[p] = tsrc[p];
   __syncthreads();
@@ -1121,8 +1131,9 @@ __global__ __launch_bounds__(128) void k_weak_div(Geo g, DevTables T, const doub
   const int xcd_ = blockIdx.x & 7, q_ = blockIdx.x >> 3;           \
   const int jj_ = q_ / g.nbxc;                                     \
   const int i = (q_ - jj_ * g.nbxc) * blockDim.x + threadIdx.x;    \
-  const int j = xcd_ * g.rows_xcdc + jj_ - g.elo;                  \
-  if (jj_ >= g.rows_xcdc || j >= g.nyc + g.ehi || i > g.nx - g.px) return; \
+  const int r_ = xcd_ * g.rows_xcdc + jj_;                         \
+  const int j = launch_row(g, r_);                                 \
+  if (jj_ >= g.rows_xcdc || r_ >= g.wrowsc || i > g.nx - g.px) return; \
   const long o = (long)(j + GH) * g.P + i;                        \
   const bool in_x = i < g.nx, in_y = j < g.ny + g.ehi;  /* an extended launch only reaches rows that exist globally */ \
   const bool below = (g.joff + j) > 0;                             \

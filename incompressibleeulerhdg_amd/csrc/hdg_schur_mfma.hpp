@@ -59,8 +59,9 @@ __device__ __forceinline__ bool schur_cell_row(const Geo& g, int& j, int& s) {
   const int xcd_ = blockIdx.x & 7, q_ = blockIdx.x >> 3;
   const int jj_ = q_ >> 1;
   s = q_ & 1;
-  j = xcd_ * g.rows_xcd + jj_ - g.elo;
-  return jj_ < g.rows_xcd && j < g.ny + g.ehi;
+  const int r_ = xcd_ * g.rows_xcd + jj_;
+  j = launch_row(g, r_);
+  return jj_ < g.rows_xcd && r_ < g.wrows;
 }
 template <int NTILES, int WAVES = HDG_SCHUR_WAVES>
 __device__ __forceinline__ void schur_stage(double* tab, const double* __restrict__ src) {
@@ -317,8 +318,9 @@ __global__ __launch_bounds__(64 * HDG_SCHUR_WAVES) void k_condense_mfma(Geo g, c
   __shared__ double tab[S::CD_TILES * 64];
   const VelBuf Brw(rw);
   const int xcd_ = blockIdx.x & 7, jj_ = blockIdx.x >> 3;
-  const int j = xcd_ * g.rows_xcdc + jj_ - g.elo;
-  if (jj_ >= g.rows_xcdc || j >= g.nyc + g.ehi) return;  // whole workgroup
+  const int r_ = xcd_ * g.rows_xcdc + jj_;
+  const int j = launch_row(g, r_);
+  if (jj_ >= g.rows_xcdc || r_ >= g.wrowsc) return;  // whole workgroup
   schur_stage<S::CD_TILES>(tab, tabs);
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63, li = l & 15, lk = l >> 4;
   const bool in_y = j < g.ny + g.ehi, below = (g.joff + j) > 0;

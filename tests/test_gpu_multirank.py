@@ -21,7 +21,10 @@ def _run_ranks(nranks, k, nx, nsteps, tmp_path, extra=(), env=None, want_logs=Fa
         outs.append(out)
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "mp_strip_worker.py"), str(r), str(nranks), token,
                                        str(k), str(nx), str(nsteps), out, *extra],
-                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=dict(os.environ, **(env or {}))))
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                                      # HDG_OVERLAP=1: the interior / boundary split around every exchange (the default over RCCL;
+                                      # off by default over the shared-memory transport these tests use) is what gets tested
+                                      env=dict(os.environ, HDG_OVERLAP="1", **(env or {}))))
     logs = []
     for pr in procs:
         try:
@@ -129,6 +132,9 @@ def test_ghost_row_bookkeeping_self_check(hip_lib, tmp_path, nranks, k, nx, opts
     m = re.search(r"\[flow check\] (\d+) skipped exchanges verified, worst relative deviation ([0-9.eE+-]+)", logs[0])
     assert m, logs[0][-2000:]
     assert int(m.group(1)) > 20 and float(m.group(2)) < 1e-12, m.group(0)
+    # the exchanges that were NOT skipped ran beside an interior launch (interior / boundary split on a second stream)
+    m2 = re.search(r"\((\d+) of them beside an interior launch\)", logs[0])
+    assert m2 and int(m2.group(1)) > 10, logs[0][-2000:]
 
 
 def test_strip_partition_at_the_benchmark_size(hip_lib, tmp_path):

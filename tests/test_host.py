@@ -255,3 +255,16 @@ def test_every_kernel_form_has_its_own_name(tmp_path):
     for frag in ("11k_adv_applyILi2ELb1E", "11k_adv_applyILi2ELb0E", "11k_edge_liftILi2ELb0ELi2ELb1E", "11k_edge_liftILi2ELb0ELi2ELb0E",
                  "10k_adv_mfmaILi4ELb1E", "10k_adv_mfmaILi4ELb0E"):
         assert any(frag in sy for sy in syms), frag
+
+
+def test_bench_watchdog_ends_an_overrunning_phase():
+    """bench.py bounds every phase of a multi-rank run (transport initialisation, warm-up, timed steps): a rank stuck in a
+    collective whose peer died ends itself with exit code 4 instead of hanging the job (torchrun tears the rest down)."""
+    import subprocess
+    import sys
+
+    code = ("import sys, time; sys.path.insert(0, %r); import bench; w = bench.Watchdog(0); w.arm('fast phase', 30); w.disarm();"
+            "w.arm('stuck collective', 1.0); time.sleep(30); sys.exit(0)" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+    assert r.returncode == 4, (r.returncode, r.stderr.decode()[-500:])
+    assert "stuck collective" in r.stderr.decode()
