@@ -1081,16 +1081,27 @@ struct Engine {
     fl.set(out, ext);
   }
   // fused smoother step (k_trace_smooth): r = cb*base + ct*(-S) v, z = Dinv r, dn = c1 v + c2 z, optional outputs
+  // mode 1: v is used as c0 * Dinv v (first step of the zero-start pre-smoother on the fly); mode 2: v is used as
+  // v + P xc (coarse correction on the fly) and x (= v) receives that sum -- k_trace_smooth / trace_stencil
   void trace_smooth(const double* v, const double* base, double cb, double ct, double c1, double c2, double* r_out,
-                    double* d_out, double* x, bool xadd, double xv) {
-    tally(LC_TRACE_SMOOTH, bL() * (1 + (base ? 1 : 0) + (r_out ? 1 : 0) + (d_out ? 1 : 0) + (x ? (xadd ? 2 : 1) : 0)));
+                    double* d_out, double* x, bool xadd, double xv, int mode = 0, double c0 = 0.0, const double* xc = nullptr,
+                    const double* xin = nullptr) {
+    if (!xin) xin = x;
+    if (mode == 2 && x == v) throw std::string("trace_smooth: mode 2 must not write the vector its neighbours read");
+    const bool same_base = base == v;  // mode 1: the right-hand side is also the stencil input
+    tally(LC_TRACE_SMOOTH, bL() * (1 + ((base && !same_base) ? 1 : 0) + (r_out ? 1 : 0) + (d_out ? 1 : 0) + (x ? ((xadd && mode != 2 && x != v) ? 2 : 1) : 0))
+                               + (mode == 2 ? 8.0 * (g.nx + 1.0) * (g.ny + 1.0) : 0.0));
     std::vector<const double*> pw;
     if (cb != 0.0) pw.push_back(base);
-    if (x && xadd) pw.push_back(x);
+    if (x && xadd && mode != 2) pw.push_back(xin);
     int ext = 0;
-    stencil_launch(v, FL, GH, true, pw, [&](const Geo& c) {
-      HDG_DISPATCH(k_trace_smooth<KK><<<corner_grid_of(c), bs(), 0, stream>>>(c, pdt(), v, base, cb, ct, c1, c2, r_out, d_out, x,
-                                                                           xadd ? 1 : 0, xv));
+    StencilAux aux{0, c0, xc, std::sqrt(dt.elen[0]), std::sqrt(dt.elen[2]), std::sqrt(dt.elen[1])};
+    const int xa = mode == 2 ? 2 : (xadd ? 1 : 0);
+    // mode 2: the vertex-grid correction is valid on the strip and 3 rows around it: results on at most 2 ghost rows
+    stencil_launch(v, FL, mode == 2 ? 2 : GH, true, pw, [&](const Geo& c) {
+      if (mode == 1) { HDG_DISPATCH(k_trace_smooth<KK, 1><<<corner_grid_of(c), bs(), 0, stream>>>(c, pdt(), v, base, cb, ct, c1, c2, r_out, d_out, x, xa, xv, aux, xin)); }
+      else if (mode == 2) { HDG_DISPATCH(k_trace_smooth<KK, 2><<<corner_grid_of(c), bs(), 0, stream>>>(c, pdt(), v, base, cb, ct, c1, c2, r_out, d_out, x, xa, xv, aux, xin)); }
+      else { HDG_DISPATCH(k_trace_smooth<KK, 0><<<corner_grid_of(c), bs(), 0, stream>>>(c, pdt(), v, base, cb, ct, c1, c2, r_out, d_out, x, xa, xv, aux, xin)); }
     }, &ext);
     fl.set(r_out, ext); fl.set(d_out, ext); fl.set(x, ext);
   }
@@ -1829,20 +1840,36 @@ struct Engine {
     const double nx_ = dot(NLv, tr_one, x, KL);
     axpby(NLv, -nx_ / tr_one_nn, tr_one, 1.0, x);
   }
-  void cheb_smooth(const double* b, double* x, bool zero_init, int its) {
+  // xc != nullptr (second application of a preconditioner cycle): the iterate is x + P xc, the prolongation of the
+  // vertex-grid correction xc, which the first step forms on the fly and stores in x (no separate k_p1_to_trace pass)
+  void cheb_smooth(const double* b, double* x, bool zero_init, int its, const double* xc = nullptr) {
     const double theta = 0.5 * (cheb_lmax + cheb_lmin), delta = 0.5 * (cheb_lmax - cheb_lmin);
     const double sigma1 = theta / delta;
     double rho = 1.0 / sigma1;
     static const bool fuse = !std::getenv("HDG_TRACE_NO_FUSE");
+    // round 3: the first step of the zero-start smoother and the prolongation folded into the stencil launches that consume
+    // them (HDG_TRACE_NO_FOLD: the separate launches of round 2)
+    static const bool fold = !std::getenv("HDG_TRACE_NO_FOLD");
+    if (xc && !(its == 2 && fuse && fold && !periodic)) { p1_to_trace(xc, x, 1.0); xc = nullptr; }
     if (its == 2 && fuse) {
       // two Chebyshev steps in two launches: operator, edge block-Jacobi and update fused (k_trace_smooth)
       const double rn = 1.0 / (2.0 * sigma1 - rho), c2_0 = 1.0 / theta, c1_1 = rn * rho, c2_1 = 2.0 * rn / delta;
-      if (zero_init) {
+      if (zero_init && fold) {
+        // ONE launch: d0 = Dinv b / theta at every edge of the stencil on the fly, x = d0 + d1
+        trace_smooth(b, b, 1.0, -1.0, c1_1, c2_1, nullptr, nullptr, x, false, 1.0, 1, c2_0);
+      } else if (zero_init) {
         trace_cheb(b, ch_d, nullptr, 0.0, c2_0);                                       // d0 = Dinv b / theta
         trace_smooth(ch_d, b, 1.0, -1.0, c1_1, c2_1, nullptr, nullptr, x, false, 1.0);  // x = d0 + d1
       } else {
-        trace_smooth(x, b, 1.0, -1.0, 0.0, c2_0, ch_r, ch_d, nullptr, false, 0.0);      // r0 = b - T x, d0
-        trace_smooth(ch_d, ch_r, 1.0, -1.0, c1_1, c2_1, nullptr, nullptr, x, true, 1.0);  // x += d0 + d1
+        if (xc) {
+          // x0 = x + P xc formed on the fly and stored in wL2 (not in x: the neighbouring threads still read x);
+          // r0 = b - T x0, d0;  then x = x0 + d0 + d1
+          trace_smooth(x, b, 1.0, -1.0, 0.0, c2_0, ch_r, ch_d, wL2, true, 0.0, 2, 0.0, xc);
+          trace_smooth(ch_d, ch_r, 1.0, -1.0, c1_1, c2_1, nullptr, nullptr, x, true, 1.0, 0, 0.0, nullptr, wL2);
+        } else {
+          trace_smooth(x, b, 1.0, -1.0, 0.0, c2_0, ch_r, ch_d, nullptr, false, 0.0);      // r0 = b - T x, d0
+          trace_smooth(ch_d, ch_r, 1.0, -1.0, c1_1, c2_1, nullptr, nullptr, x, true, 1.0);  // x += d0 + d1
+        }
       }
       return;
     }
@@ -2018,8 +2045,7 @@ struct Engine {
     k_trace_to_p1<<<corner_grid_all(), bs(), 0, stream>>>(g_all, NL, wL2, mg_b[0], dt.elen[0], dt.elen[2], dt.elen[1], partial);
     if (mg_distributed()) {
       vcycle_distributed_top();
-      p1_to_trace(mg_x[0], z, 1.0);
-      cheb_smooth(r, z, false, nsm);
+      cheb_smooth(r, z, false, nsm, mg_x[0]);
       return;
     }
     if (mg_gather) {
@@ -2031,8 +2057,7 @@ struct Engine {
       k_p1_assemble<<<vec_blocks(nvtx), 256, 0, stream>>>(comm->size, g.ny, g.nx + 1, mg_gather, mg_b[0], partial);
     }
     run_vcycle();
-    p1_to_trace(mg_x[0], z, 1.0);
-    cheb_smooth(r, z, false, nsm);
+    cheb_smooth(r, z, false, nsm, mg_x[0]);
   }
   void setup_trace_solver() {
     // null-space vector

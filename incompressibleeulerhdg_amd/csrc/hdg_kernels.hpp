@@ -1149,10 +1149,39 @@ __device__ __forceinline__ void load_tr(const double* __restrict__ l, const Geo&
 
 // (-S) lam at the three edges (H, V, D) attached to grid corner (i, j): sums over the <= 2 cells per edge.
 // own[] receives lam at those edges in local-edge order (H0, D0, V0) of cell L(i,j).
-template <int K>
+// MODE (round 3: two launches of the trace preconditioner folded into their consumers):
+//   0  the input vector as stored
+//   1  PRE:  v = c0 * Dinv * lam at every edge the stencil reads (edge block-Jacobi on the fly): the first step of the
+//      zero-start Chebyshev pre-smoother, d0 = Dinv b / theta, never goes through memory (was k_trace_cheb + its vector)
+//   2  POST: v = lam + P xc at every edge the stencil reads (prolongation of the vertex-grid correction on the fly: was
+//      k_p1_to_trace, a read-modify-write pass over z)
+struct StencilAux {
+  int j;                     // corner row of this thread
+  double c0;                 // MODE 1
+  const double* xc;          // MODE 2: global (replicated) vertex vector, row pitch nx + 1
+  double sH, sV, sD;         // MODE 2: sqrt(edge length) per edge type
+};
+template <int NL>
+__device__ __forceinline__ void edge_dinv(const double* __restrict__ Dm, double c0, double* v) {
+  double z[NL];
+#pragma unroll
+  for (int a = 0; a < NL; a++) {
+    double acc = 0.0;
+#pragma unroll
+    for (int b = 0; b < NL; b++) acc = fma(Dm[a * NL + b], v[b], acc);
+    z[a] = c0 * acc;
+  }
+#pragma unroll
+  for (int a = 0; a < NL; a++) v[a] = z[a];
+}
+__device__ __forceinline__ void edge_prolong(double va, double vb, double sl, double* v) {
+  v[0] += sl * 0.5 * (va + vb);
+  v[1] += sl * 0.57735026918962576451 * 0.5 * (vb - va);
+}
+template <int K, int MODE = 0>
 __device__ __forceinline__ void trace_stencil(const Geo& g, const DevTables& T, const double* __restrict__ lam, long o, int i,
                                               bool in_x, bool in_y, bool below, double* own, double* yH, double* yV,
-                                              double* yD) {
+                                              double* yD, const StencilAux aux = StencilAux{0, 0.0, nullptr, 0.0, 0.0, 0.0}) {
   const bool left = i > 0 || g.px;
   const long oL = o - i + xm1(g, i), oR = o - i + xp1(g, i);
   constexpr int NL = Dim<K>::NL, NT = 3 * NL;
@@ -1174,6 +1203,47 @@ __device__ __forceinline__ void trace_stencil(const Geo& g, const DevTables& T, 
   load_tr<NL>(lam, g, 1, oR - g.P, uB + 2 * NL);  //           V(i+1,j-1)
   load_tr<NL>(lam, g, 0, oL + g.P, uC);           // U(i-1,j): H(i-1,j+1)
   load_tr<NL>(lam, g, 2, oL, uC + NL);            //           D(i-1,j)
+  if (MODE == 1) {
+    // block-Jacobi variant of an edge: H edges on the bottom / top boundary and V edges on the left / right boundary have
+    // one cell only (variants 1 / 2); the row-dependent choice is wave uniform, the column-dependent one is not, so the
+    // interior table is applied to every lane and the two boundary columns redo their V edges
+    const int J = g.joff + aux.j;
+    const int vH0 = J == 0 ? 1 : (J == g.nyg ? 2 : 0), vH1 = (J + 1) == g.nyg ? 2 : 0;
+    const int vV0 = g.px ? 0 : (i == 0 ? 1 : (i == g.nx ? 2 : 0)), vV1 = g.px ? 0 : ((i + 1) == g.nx ? 2 : 0);
+    edge_dinv<NL>(T.trDinv[0][vH0], aux.c0, own);
+    edge_dinv<NL>(T.trDinv[2][0], aux.c0, own + NL);
+    edge_dinv<NL>(T.trDinv[0][vH1], aux.c0, uA);
+    edge_dinv<NL>(T.trDinv[2][0], aux.c0, uB + NL);
+    edge_dinv<NL>(T.trDinv[0][vH1], aux.c0, uC);
+    edge_dinv<NL>(T.trDinv[2][0], aux.c0, uC + NL);
+    if (vV0 == 0) edge_dinv<NL>(T.trDinv[1][0], aux.c0, own + 2 * NL); else edge_dinv<NL>(T.trDinv[1][vV0], aux.c0, own + 2 * NL);
+    if (vV1 == 0) {
+      edge_dinv<NL>(T.trDinv[1][0], aux.c0, uA + 2 * NL);
+      edge_dinv<NL>(T.trDinv[1][0], aux.c0, uB + 2 * NL);
+    } else {
+      edge_dinv<NL>(T.trDinv[1][vV1], aux.c0, uA + 2 * NL);
+      edge_dinv<NL>(T.trDinv[1][vV1], aux.c0, uB + 2 * NL);
+    }
+  }
+  if (MODE == 2) {
+    // vertices of the 3 x 3 patch that the nine edges touch (clamped: what a clamped index delivers belongs to an edge
+    // that does not exist and is masked below or multiplied by a cell that does not exist)
+    const int st = g.nx + 1;
+    const long J = g.joff + aux.j;
+    const long Jm = J > 0 ? J - 1 : 0, Jp = J < g.nyg ? J + 1 : g.nyg;
+    const int im = i > 0 ? i - 1 : 0, ip = i < g.nx ? i + 1 : g.nx;
+    const double v00 = aux.xc[J * st + i], v10 = aux.xc[J * st + ip], v01 = aux.xc[Jp * st + i], v11 = aux.xc[Jp * st + ip];
+    const double v1m = aux.xc[Jm * st + ip], vm1 = aux.xc[Jp * st + im];
+    edge_prolong(v00, v10, aux.sH, own);           // H(i,j)
+    edge_prolong(v10, v01, aux.sD, own + NL);      // D(i,j)
+    edge_prolong(v00, v01, aux.sV, own + 2 * NL);  // V(i,j)
+    edge_prolong(v01, v11, aux.sH, uA);            // H(i,j+1)
+    edge_prolong(v10, v11, aux.sV, uA + 2 * NL);   // V(i+1,j)
+    edge_prolong(v1m, v00, aux.sD, uB + NL);       // D(i,j-1)
+    edge_prolong(v1m, v10, aux.sV, uB + 2 * NL);   // V(i+1,j-1)
+    edge_prolong(vm1, v01, aux.sH, uC);            // H(i-1,j+1)
+    edge_prolong(v00, vm1, aux.sD, uC + NL);       // D(i-1,j)
+  }
 #pragma unroll
   for (int m = 0; m < NL; m++) {
     if (!in_x) own[m] = 0.0;
@@ -1231,15 +1301,19 @@ __global__ __launch_bounds__(128) void k_trace_apply(Geo g, DevTables T, const d
 // v is read through the stencil by neighbouring threads, so dn goes to a DIFFERENT buffer (d_out != v).
 // The two-step Chebyshev smoother of the trace preconditioner is then 2 launches and 5-8 vector passes
 // instead of 3-4 launches and 11-15 passes (Engine::cheb_smooth).
-template <int K>
+// MODE 1 (v = c0 Dinv v_stored on the fly) / MODE 2 (v = v_stored + P xc on the fly; xadd == 2: x receives that v and must
+// be a vector OTHER than v, which the neighbouring threads are still reading): see trace_stencil
+template <int K, int MODE>
 __global__ __launch_bounds__(128) void k_trace_smooth(Geo g, DevTables T, const double* __restrict__ v,
                                                        const double* __restrict__ base, double cb, double ct, double c1,
                                                        double c2, double* __restrict__ r_out, double* __restrict__ d_out,
-                                                       double* __restrict__ x, int xadd, double xv) {
+                                                       double* x, int xadd, double xv, StencilAux aux,
+                                                       const double* xin /* may alias x */) {
   constexpr int NL = Dim<K>::NL, NT = 3 * NL;
   HDG_CORNER_PROLOGUE
   double y[3][NL], own[NT];  // y[t]: t = 0 H, 1 V, 2 D  (plane order of the trace layout)
-  trace_stencil<K>(g, T, v, o, i, in_x, in_y, below, own, y[0], y[1], y[2]);
+  aux.j = j;
+  trace_stencil<K, MODE>(g, T, v, o, i, in_x, in_y, below, own, y[0], y[1], y[2], aux);
   const bool valid[3] = {in_x, in_y, in_x && in_y};
   const int ownoff[3] = {0, 2 * NL, NL};  // own[] is in local-edge order (H, D, V)
   const int var[3] = {(g.joff + j == 0) ? 1 : (g.joff + j == g.nyg ? 2 : 0), g.px ? 0 : ((i == 0) ? 1 : (i == g.nx ? 2 : 0)), 0};
@@ -1250,7 +1324,7 @@ __global__ __launch_bounds__(128) void k_trace_smooth(Geo g, DevTables T, const 
     for (int m = 0; m < NL; m++) {
       const long idx = ((long)t * NL + m) * g.G + o;
       bb[t][m] = (base && valid[t]) ? cb * base[idx] : 0.0;
-      xo[t][m] = (x && xadd && valid[t]) ? x[idx] : 0.0;
+      xo[t][m] = (x && xadd == 1 && valid[t]) ? xin[idx] : 0.0;  // xin == x unless the old value lives in another vector
     }
 #pragma unroll
   for (int t = 0; t < 3; t++) {
@@ -1266,7 +1340,7 @@ __global__ __launch_bounds__(128) void k_trace_smooth(Geo g, DevTables T, const 
       const double dn = fma(c1, vo, c2 * z[m]);
       if (r_out) r_out[idx] = r[m];
       if (d_out) d_out[idx] = dn;
-      if (x) x[idx] = xo[t][m] + fma(xv, vo, dn);
+      if (x) x[idx] = xadd == 2 ? vo : xo[t][m] + fma(xv, vo, dn);
     }
   }
 }
