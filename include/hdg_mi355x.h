@@ -91,6 +91,19 @@ typedef struct hdg_handle hdg_handle;
  * (hdg_imex.py:29-255, hdg_implicit.py:17-50, common.py:23-73): spaces, 1/h_F, local operator tables,
  * all persistent stage vectors (zero-initialised), solver workspaces. */
 int hdg_create(const hdg_config* cfg, hdg_handle** out);
+/* General affine triangulation: `UnitDiskMesh(refinement_level)` of src/driver.py:184-185, the
+ * mesh of the Kelvin-Helmholtz set-up (src/model_problems.py:108-131), or any conforming triangulation: coords (n_vertices, 2),
+ * cells (n_cells, 3) vertex numbers.  cfg.nx / ny / periodic / length are ignored.  The handle serves the same entry points
+ * (state, per-solve calls, hdg_step / hdg_run_separable, norms, node coordinates); per-element geometry replaces the two
+ * shared element shapes: assembled solution-independent operators + hand-written advection / reconstruction kernels, GMRES
+ * with element block-Jacobi for the tentative velocity (hdg_imex.py:223-255), condensation + CG with the edge block-Jacobi
+ * (ASMStarPC of hdg_imex.py:143-152, no coarse space) for the pressure.  Single rank, projection method, no tracer.
+ * Numbering at the boundary: cells as given; local edge l joins vertices l and (l+1)%3 of its cell; edges in order of first
+ * appearance while walking the cells, directed from the lower to the higher vertex number; velocity / pressure nodes: the
+ * lattice of the structured path on x = v0 + (v1 - v0) xi + (v2 - v0) eta; trace nodes along the edge direction.
+ * hdg_general_topology: edge_vertices (n_edges, 2) and edge_cells (n_edges, 2; -1 = boundary) in that numbering. */
+int hdg_create_general(const hdg_config* cfg, int n_vertices, const double* coords, int n_cells, const int* cells, hdg_handle** out);
+int hdg_general_topology(const hdg_handle* h, int* edge_vertices, int* edge_cells);
 int hdg_destroy(hdg_handle* h);
 const char* hdg_last_error(const hdg_handle* h); /* h may be NULL for create errors */
 

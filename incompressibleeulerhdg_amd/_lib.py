@@ -73,7 +73,7 @@ class hdg_config(C.Structure):
 
 def build_library(force=False, verbose=False):
     """Compile the HIP engine for gfx950 into the package directory (in-tree, travels with gpurun)."""
-    srcs = [SRC, HEADER] + [os.path.join(_HERE, "csrc", f) for f in ("hdg_kernels.hpp", "hdg_schur_mfma.hpp", "hdg_tables.hpp", "hdg_comm.hpp", "hdg_cg.hpp")]
+    srcs = [SRC, HEADER] + [os.path.join(_HERE, "csrc", f) for f in ("hdg_kernels.hpp", "hdg_schur_mfma.hpp", "hdg_tables.hpp", "hdg_comm.hpp", "hdg_cg.hpp", "hdg_general.hpp", "hdg_general_kernels.hpp")]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -97,6 +97,8 @@ SIGNATURES = {
     "hdg_create": [C.POINTER(hdg_config), C.POINTER(_h)],
     "hdg_create_distributed": [C.POINTER(hdg_config), C.c_int, C.c_int, C.c_int, C.c_char_p, C.POINTER(_h)],
     "hdg_rccl_unique_id": [C.c_char_p],
+    "hdg_create_general": [C.POINTER(hdg_config), C.c_int, _dp, C.c_int, _ip, C.POINTER(_h)],
+    "hdg_general_topology": [_h, _ip, _ip],
     "hdg_destroy": [_h],
     "hdg_get_sizes": [_h, _lp, _lp, _ip, _ip, _ip],
     "hdg_set_state": [_h, _dp, _dp],
@@ -184,8 +186,8 @@ class Engine:
         self.lib = load_library()
         cfg = hdg_config()
         s = int(kw["nstages"])
-        cfg.nx = int(kw["nx"])
-        cfg.ny = int(kw.get("ny", kw["nx"]))
+        cfg.nx = int(kw.get("nx", 1))
+        cfg.ny = int(kw.get("ny", kw.get("nx", 1)))
         cfg.degree = int(kw["degree"])
         cfg.dt = float(kw["dt"])
         cfg.flux_upwind = 1 if kw.get("flux", "upwind") == "upwind" else 0
@@ -230,7 +232,16 @@ class Engine:
         self.cfg = cfg
         self.h = _h()
         self.rank, self.nranks = int(kw.get("rank", 0)), int(kw.get("nranks", 1))
-        if self.nranks > 1:
+        self.general = kw.get("vertices") is not None
+        if self.general:
+            # general affine triangulation (hdg_create_general): vertices (nv, 2), cells (nc, 3)
+            self._vertices = np.ascontiguousarray(kw["vertices"], dtype=np.float64)
+            self._cells = np.ascontiguousarray(kw["cells"], dtype=np.int32)
+            if self._vertices.ndim != 2 or self._vertices.shape[1] != 2 or self._cells.ndim != 2 or self._cells.shape[1] != 3:
+                raise ValueError("general mesh: vertices (nv, 2) and cells (nc, 3) expected")
+            rc = self.lib.hdg_create_general(C.byref(cfg), len(self._vertices), _ptr(self._vertices), len(self._cells),
+                                             self._cells.ctypes.data_as(_ip), C.byref(self.h))
+        elif self.nranks > 1:
             backend = {"rccl": HDG_COMM_RCCL, "shm": HDG_COMM_SHM}[kw.get("comm_backend", "rccl")]
             token = kw["comm_token"]
             token = token if isinstance(token, bytes) else str(token).encode()
@@ -251,6 +262,8 @@ class Engine:
         # dimension of the GLOBAL mixed state (Q, p, lambda) advanced per step
         nxg, nyg = cfg.nx, cfg.ny
         self.n_total = 2 * nxg * nyg * (2 * self.n_u + self.n_p) + (3 * nxg * nyg + (0 if cfg.periodic else nxg + nyg)) * self.n_l
+        if self.general:
+            self.n_total = self.n_cells * (2 * self.n_u + self.n_p) + self.n_edges * self.n_l
 
     def _ck(self, rc):
         if rc != 0:
@@ -438,6 +451,13 @@ class Engine:
         name = C.create_string_buffer(16)
         self._ck(self.lib.hdg_get_comm_info(self.h, C.byref(r), C.byref(n), C.byref(t), name))
         return r.value, n.value, t.value, name.value.decode()
+
+    def general_topology(self):
+        """(edge_vertices (n_edges, 2), edge_cells (n_edges, 2; -1 = boundary)) of a general-mesh engine"""
+        ev = np.zeros((self.n_edges, 2), dtype=np.int32)
+        ec = np.zeros((self.n_edges, 2), dtype=np.int32)
+        self._ck(self.lib.hdg_general_topology(self.h, ev.ctypes.data_as(_ip), ec.ctypes.data_as(_ip)))
+        return ev, ec
 
     def set_kernel_timing(self, on):
         self._ck(self.lib.hdg_set_kernel_timing(self.h, 1 if on else 0))

@@ -32,6 +32,8 @@
 #include "hdg_schur_mfma.hpp"
 #include "hdg_cg.hpp"
 #include "hdg_tables.hpp"
+#include "hdg_general.hpp"
+#include "hdg_general_kernels.hpp"
 
 namespace hdg {
 
@@ -242,6 +244,124 @@ struct Engine {
   // streaming cache policy for vectors that exceed the Infinity Cache together with their partners
   bool big(long n) const { return n * 8L >= (96L << 20); }
 
+  // ------------------------------------------------------------------ general affine triangulations
+  // hdg_general.hpp builds topology, per-cell local matrices and the assembled solution-independent operators on the host;
+  // here they are uploaded and every kernel wrapper below gets a `general` branch: one CSR kernel for the assembled
+  // operators, k_g_adv / k_g_precon for the two solution-dependent forms.  The solvers (GMRES with element block-Jacobi,
+  // condensation + CG with edge block-Jacobi + back-substitution) and the step orchestration are the structured engine's.
+  bool general = false;
+  GMesh* gm = nullptr;
+  GeneralTables* gtab = nullptr;
+  GeneralOps gops;
+  std::vector<CellLocal> gloc;
+  struct GDev {
+    DevCsr Pi, Wdiv, Bdiv, Gp, Gl, Yw, Yp, S, Auu, Aup, Apu, App, Wu, Wp, Dtr, Rq, Rp, Rb, Cq, Cqi, Cp, Cpi, Cl, Cli;
+  } gd;
+  std::vector<DevCsr> gdinv;  // element block-Jacobi per stage
+  GGeo ggeo;
+  const double *d_one_p = nullptr, *d_int_p = nullptr, *d_one_l = nullptr;
+  const int* upload_ints(const std::vector<int>& v) {
+    void* p = nullptr;
+    HIPCHECK(hipMalloc(&p, sizeof(int) * std::max<size_t>(v.size(), 1)));
+    allocs.push_back(p);
+    HIPCHECK(hipMemcpy(p, v.data(), sizeof(int) * v.size(), hipMemcpyHostToDevice));
+    return (const int*)p;
+  }
+  DevCsr upload_csr(const Csr& m) {
+    DevCsr d;
+    d.nrows = m.nrows; d.ncols = m.ncols; d.nnz = (long)m.val.size();
+    d.rowptr = upload_ints(m.rowptr);
+    d.col = upload_ints(m.col);
+    d.val = upload(m.val.empty() ? dvec(1, 0.0) : m.val);
+    return d;
+  }
+  // y = beta y + alpha A x
+  void csr(const DevCsr& A, const double* x, double alpha, double beta, double* y) {
+    tally(LC_OTHER, 12.0 * A.nnz + 8.0 * (A.ncols + A.nrows * (beta != 0.0 ? 2 : 1)));
+    k_csr_apply<<<(A.nrows + 127) / 128, 128, 0, stream>>>(A, x, alpha, beta, y);
+    fl.set(y, 0);
+  }
+  Engine(const hdg_config& c, Comm* comm_, int nv, const double* coords, int nc, const int* cells) : cfg(c), comm(comm_) {
+    if (c.degree < 1 || c.degree > 4) throw std::string("degree must be in 1..4");
+    if (c.nstages < 1 || c.nstages > HDG_MAX_STAGES) throw std::string("nstages out of range");
+    if (!(c.dt > 0)) throw std::string("dt must be positive");
+    if (comm->size != 1) throw std::string("general meshes are implemented for a single rank");
+    if (!c.use_projection) throw std::string("general meshes: the projection method only (no monolithic solve)");
+    HIPCHECK(hipSetDevice(c.device));
+    HIPCHECK(hipStreamCreate(&stream));
+    try {
+      construct_general(c, nv, coords, nc, cells);
+    } catch (...) {
+      release();
+      throw;
+    }
+  }
+  void construct_general(const hdg_config& c, int nv, const double* coords, int nc, const int* cells) {
+    general = true;
+    K = c.degree; s = c.nstages;
+    NU = n_scalar(K + 1); NP = n_scalar(K); NL = K + 1; NE = K + 2; NX = 2 * NU + NP;
+    // solvers of this path: GMRES(m) with the element block-Jacobi, CG with the edge block-Jacobi (the two-level
+    // preconditioners of the structured engine lean on the two shared shapes / the vertex grid)
+    cfg.tent_precond = 0; cfg.tent_solver = 0; cfg.trace_precond = 0; cfg.periodic = 0;
+    cfg.gmres_restart = std::max(cfg.gmres_restart, 30);
+    gm = new GMesh();
+    gm->build(nv, coords, nc, cells);
+    gtab = new GeneralTables(K, c.tau, c.alpha_penalty, c.equispaced_nodes);
+    assemble_general(*gtab, *gm, gops, gloc);
+    // the structured-mesh descriptor only sizes scratch buffers and vector kernels here
+    g = Geo{};
+    g.nx = 1; g.ny = 1; g.P = 16; g.nyg = 1; g.joff = 0; g.nyc = 1; g.G = 16; g.R = 1; g.h = 1.0; g.nbx = 1; g.nbxc = 1;
+    g.rows_xcd = 1; g.rows_xcdc = 1; g.wrows = 1; g.wrowsc = 1;
+    g.Nc = gm->nc;
+    g_all = g;
+    Ldom = 1.0;
+    NQ = (long)gm->nc * 2 * NU; NPv = (long)gm->nc * NP; NLv = (long)gm->ne * NL;
+    NQb = NQ; NPb = NPv; NLb = NLv;
+    tab = new Tables(K, 1.0, c.tau, c.alpha_penalty, c.equispaced_nodes);  // shared reference data only
+    alloc_state();
+    // device copies
+    gd.Pi = upload_csr(gops.Pi); gd.Wdiv = upload_csr(gops.Wdiv); gd.Bdiv = upload_csr(gops.Bdiv); gd.Gp = upload_csr(gops.Gp);
+    gd.Gl = upload_csr(gops.Gl); gd.Yw = upload_csr(gops.Yw); gd.Yp = upload_csr(gops.Yp); gd.S = upload_csr(gops.S);
+    gd.Auu = upload_csr(gops.Auu); gd.Aup = upload_csr(gops.Aup); gd.Apu = upload_csr(gops.Apu); gd.App = upload_csr(gops.App);
+    gd.Wu = upload_csr(gops.Wu); gd.Wp = upload_csr(gops.Wp); gd.Dtr = upload_csr(gops.Dtr); gd.Rq = upload_csr(gops.Rq);
+    gd.Rp = upload_csr(gops.Rp); gd.Rb = upload_csr(gops.Rb); gd.Cq = upload_csr(gops.Cq); gd.Cqi = upload_csr(gops.Cqi);
+    gd.Cp = upload_csr(gops.Cp); gd.Cpi = upload_csr(gops.Cpi); gd.Cl = upload_csr(gops.Cl); gd.Cli = upload_csr(gops.Cli);
+    d_one_p = upload(gops.one_p); d_int_p = upload(gops.int_p); d_one_l = upload(gops.one_l);
+    gdinv.assign((size_t)s, DevCsr());
+    {
+      const GMesh& M = *gm;
+      dvec isd((size_t)M.nc), celen((size_t)3 * M.nc), cenx((size_t)3 * M.nc), ceny((size_t)3 * M.nc);
+      std::vector<int> cnbr((size_t)3 * M.nc), ctab((size_t)3 * M.nc), ntab((size_t)3 * M.nc, 0);
+      for (int cc = 0; cc < M.nc; cc++) {
+        isd[(size_t)cc] = 1.0 / std::sqrt(M.detJ[(size_t)cc]);
+        for (int l = 0; l < 3; l++) {
+          const int e = M.cedge[3 * (size_t)cc + l];
+          const int side = M.ecell[2 * (size_t)e] == cc ? 0 : 1;
+          const int cn = M.ecell[2 * (size_t)e + (1 - side)];
+          cnbr[3 * (size_t)cc + l] = cn;
+          ctab[3 * (size_t)cc + l] = l * 2 + M.cflip[3 * (size_t)cc + l];
+          if (cn >= 0) {
+            const int ln = M.elocal[2 * (size_t)e + (1 - side)];
+            ntab[3 * (size_t)cc + l] = ln * 2 + M.cflip[3 * (size_t)cn + ln];
+          }
+          celen[3 * (size_t)cc + l] = M.elen[(size_t)e]; cenx[3 * (size_t)cc + l] = M.enx[(size_t)e]; ceny[3 * (size_t)cc + l] = M.eny[(size_t)e];
+        }
+      }
+      ggeo.nc = M.nc;
+      ggeo.inv_sdet = upload(isd); ggeo.detJ = upload(M.detJ); ggeo.Jinv = upload(M.Jinv);
+      ggeo.cnbr = upload_ints(cnbr); ggeo.ctab = upload_ints(ctab); ggeo.ntab = upload_ints(ntab);
+      ggeo.csig = upload(M.csig); ggeo.celen = upload(celen); ggeo.cenx = upload(cenx); ggeo.ceny = upload(ceny);
+      ggeo.cw = upload(gtab->cw); ggeo.cPhi = upload(gtab->cPhi); ggeo.cGxi = upload(gtab->cGxi); ggeo.cGeta = upload(gtab->cGeta);
+      ggeo.ew = upload(gtab->ew); ggeo.ePhi = upload(gtab->ePhi); ggeo.eGxi = upload(gtab->eGxi); ggeo.eGeta = upload(gtab->eGeta);
+      ggeo.nqc = gtab->nqc; ggeo.nqe = gtab->nqe; ggeo.alpha = c.alpha_penalty;
+    }
+    setup_trace_solver();
+    HIPCHECK(hipStreamSynchronize(stream));
+  }
+  [[noreturn]] void general_unsupported(const char* what) const {
+    throw std::string("general meshes: ") + what + " is not implemented (structured meshes only)";
+  }
+
   // ------------------------------------------------------------------ construction
   Engine(const hdg_config& c, Comm* comm_) : cfg(c), comm(comm_) {
     if (c.degree < 1 || c.degree > 4) throw std::string("degree must be in 1..4");
@@ -276,6 +396,8 @@ struct Engine {
     if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; }
     delete tab;
     tab = nullptr;
+    delete gm; gm = nullptr;
+    delete gtab; gtab = nullptr;
   }
   void construct(const hdg_config& c) {
     K = c.degree;
@@ -888,7 +1010,7 @@ struct Engine {
   // HDG_NO_MFMA_SCHUR: the per-thread kernels at every degree (A/B timing, parity of the two formulations)
   bool use_mfma_schur() const {
     static const bool off = std::getenv("HDG_NO_MFMA_SCHUR") != nullptr;
-    return !off && cfg.degree >= mfma_min_degree() && !periodic;  // the matrix-core kernels do not wrap column indices
+    return !off && cfg.degree >= mfma_min_degree() && !periodic && !general;  // the matrix-core kernels do not wrap column indices
   }
   void ensure_schur_tables(PSet& ps) {
     if (ps.bsm[0]) return;
@@ -909,7 +1031,7 @@ struct Engine {
   std::vector<double*> liftm_hyb0, liftm_hyb1;         // per stage: hybrid preconditioner
   bool use_mfma_lift() const {
     static const bool off = std::getenv("HDG_NO_MFMA_LIFT") != nullptr;
-    return !off && cfg.degree >= mfma_min_degree() && !periodic;  // the matrix-core kernels do not wrap column indices
+    return !off && cfg.degree >= mfma_min_degree() && !periodic && !general;  // the matrix-core kernels do not wrap column indices
   }
   // HDG_MFMA_K2 (experiment): the matrix-core kernels at k = 2 as well (north_star: "MFMA at k >= 2")
   static int mfma_min_degree() { static const int d = std::getenv("HDG_MFMA_K2") ? 2 : 3; return d; }
@@ -923,6 +1045,7 @@ struct Engine {
     }
   }
   void bdm(const double* in, double* out) {
+    if (general) { csr(gd.Pi, in, 1.0, 0.0, out); return; }
     const int ext = stencil_in(in, FQ);
     const Geo gx = g_ext(ext);
     fl.set(out, ext);
@@ -981,6 +1104,7 @@ struct Engine {
     fl.set(out, ext); fl.set(chd_, ext);
   }
   void bdm_T(const double* in, double* out) {
+    if (general) general_unsupported("the transposed lift (additive preconditioner)");
     const int ext = stencil_in(in, FQ);
     const Geo gx = g_ext(ext);
     tally(LC_LIFT, 2 * bQ());
@@ -991,6 +1115,11 @@ struct Engine {
     KTimed kt_(*this, T_KADV, fl.active() && ((cfg.tent_solver == 1) == (bsub != nullptr)));
     const double up = cfg.flux_upwind ? 1.0 : 0.0;
     tally(LC_ADV, bQ() * (bsub ? 4 : 3));
+    if (general) {
+      HDG_DISPATCH(k_g_adv<KK><<<(ggeo.nc + 63) / 64, 64, 0, stream>>>(ggeo, x, qstar, out, gamma, up, bsub));
+      fl.set(out, 0);
+      return;
+    }
     // k >= 3: the whole operator on the matrix cores (k_adv_mfma); HDG_NO_MFMA_ADV falls back to the per-thread kernels
     static const bool no_mfma_adv = std::getenv("HDG_NO_MFMA_ADV") != nullptr;
     const bool mfma = !no_mfma_adv && cfg.degree >= mfma_min_degree() && !periodic;
@@ -1038,6 +1167,12 @@ struct Engine {
   }
   void pgrad(const double* a, double ca, const double* b, double cb, const double* p, const double* l, double gamma,
              double* out) {
+    if (general) {
+      lincomb(NQ, {{a, a ? ca : 0.0}, {b, b ? cb : 0.0}}, out);
+      csr(gd.Gp, p, gamma, 1.0, out);
+      csr(gd.Gl, l, gamma, 1.0, out);
+      return;
+    }
     halo_L(l);
     tally(LC_RHS, bQ() * (1 + (a ? 1 : 0) + (b ? 1 : 0)) + bP() + bL());
     if (use_mfma_schur()) {
@@ -1052,6 +1187,7 @@ struct Engine {
     HDG_DISPATCH(k_pgrad<KK><<<cell_grid(), bs(), 0, stream>>>(g, dt, a, ca, b, cb, p, l, gamma, out));
   }
   void weak_div(const double* q, double sc, double* out, bool broken) {
+    if (general) { csr(broken ? gd.Bdiv : gd.Wdiv, q, sc, 0.0, out); return; }
     if (!broken) halo_Q(q);
     tally(LC_WDIV, bQ() + bP());
     if (use_mfma_schur()) {
@@ -1071,6 +1207,11 @@ struct Engine {
     else { HDG_DISPATCH(k_weak_div<KK, false><<<cell_grid(), bs(), 0, stream>>>(g, dt, q, sc, out)); }
   }
   void trace_apply(const double* lam, const double* base, double cb, double ct, double* out, int max_ext = GH) {
+    if (general) {
+      if (base && cb != 0.0) { if (out != base) copy(out, base, NLv); if (cb != 1.0) axpby(NLv, 0.0, out, cb, out); csr(gd.S, lam, ct, 1.0, out); }
+      else csr(gd.S, lam, ct, 0.0, out);
+      return;
+    }
     tally(LC_TRACE_APPLY, bL() * (2 + ((base && cb != 0.0) ? 1 : 0)));
     std::vector<const double*> pw;
     if (cb != 0.0) pw.push_back(base);
@@ -1086,6 +1227,7 @@ struct Engine {
   void trace_smooth(const double* v, const double* base, double cb, double ct, double c1, double c2, double* r_out,
                     double* d_out, double* x, bool xadd, double xv, int mode = 0, double c0 = 0.0, const double* xc = nullptr,
                     const double* xin = nullptr) {
+    if (general) general_unsupported("the fused trace smoother (multigrid preconditioner)");
     if (!xin) xin = x;
     if (mode == 2 && x == v) throw std::string("trace_smooth: mode 2 must not write the vector its neighbours read");
     const bool same_base = base == v;  // mode 1: the right-hand side is also the stencil input
@@ -1106,6 +1248,11 @@ struct Engine {
     fl.set(r_out, ext); fl.set(d_out, ext); fl.set(x, ext);
   }
   void trace_cheb(const double* r, double* d, double* x, double c1, double c2, bool assign = false) {
+    if (general) {
+      csr(gd.Dtr, r, c2, c1, d);  // d = c1 d + c2 Dinv r
+      if (x) { if (assign) copy(x, d, NLv); else axpby(NLv, 1.0, d, 1.0, x); }
+      return;
+    }
     int ext = pw_in(r, GH - 1);
     if (c1 != 0.0) ext = pw_in(d, ext);
     if (x && !assign) ext = pw_in(x, ext);
@@ -1123,6 +1270,12 @@ struct Engine {
     fl.set(z, ext);
   }
   void condense(const double* rw, const double* rp, const double* rl, double* out) {
+    if (general) {
+      if (rl) axpby(NLv, -1.0, rl, 0.0, out); else zero(out, NLv);
+      if (rw) csr(gd.Yw, rw, 1.0, 1.0, out);
+      if (rp) csr(gd.Yp, rp, 1.0, 1.0, out);
+      return;
+    }
     if (rw) halo_Q(rw);
     if (rp) halo_P(rp);
     tally(LC_CONDENSE, (rw ? bQ() : 0.0) + (rp ? bP() : 0.0) + bL() * (rl ? 2 : 1));
@@ -1151,6 +1304,13 @@ struct Engine {
     else { HDG_DISPATCH(k_condense<KK, true, true><<<corner_grid(), bs(), 0, stream>>>(g, pdt(), rw, rp, rl, out)); }
   }
   void backsub(const double* rw, const double* rp, const double* lam, double* u, double* phi) {
+    if (general) {
+      csr(gd.Wu, lam, 1.0, 0.0, u);    // Wu = -W
+      csr(gd.Wp, lam, 1.0, 0.0, phi);
+      if (rw) { csr(gd.Auu, rw, 1.0, 1.0, u); csr(gd.Apu, rw, 1.0, 1.0, phi); }
+      if (rp) { csr(gd.Aup, rp, 1.0, 1.0, u); csr(gd.App, rp, 1.0, 1.0, phi); }
+      return;
+    }
     halo_L(lam);
     tally(LC_BACKSUB, (rw ? bQ() : 0.0) + (rp ? bP() : 0.0) + bL() + bQ() + bP());
     if (use_mfma_schur() && (rw || rp)) {
@@ -1175,23 +1335,32 @@ struct Engine {
     else { HDG_DISPATCH(k_backsub<KK, true, true><<<cell_grid(), bs(), 0, stream>>>(g, pdt(), rw, rp, lam, u, phi)); }
   }
   void gamma_psi(const double* u, const double* phi, const double* lam, double* out) {
+    if (general) general_unsupported("the monolithic (unsplit) solve");
     if (lam) halo_L(lam);
     tally(LC_OTHER, (u ? bQ() : 0.0) + (phi ? bP() : 0.0) + (lam ? bL() : 0.0) + bP());
     HDG_DISPATCH(k_gamma_psi<KK><<<cell_grid(), bs(), 0, stream>>>(g, dt, u, phi, lam, out));
   }
   void gamma_mu(const double* u, const double* phi, const double* lam, double* out) {
+    if (general) general_unsupported("the monolithic (unsplit) solve");
     if (u) halo_Q(u);
     if (phi) halo_P(phi);
     tally(LC_OTHER, (u ? bQ() : 0.0) + (phi ? bP() : 0.0) + bL() * (lam ? 2 : 1));
     HDG_DISPATCH(k_gamma_mu<KK><<<corner_grid(), bs(), 0, stream>>>(g, dt, u, phi, lam, out));
   }
   void trace_recon(const double* Q, const double* p, double* out) {
+    if (general) { csr(gd.Rq, Q, 1.0, 0.0, out); csr(gd.Rp, p, 1.0, 1.0, out); return; }
     halo_Q(Q);
     halo_P(p);
     tally(LC_OTHER, bQ() + bP() + bL());
     HDG_DISPATCH(k_trace_recon<KK><<<corner_grid(), bs(), 0, stream>>>(g, dt, Q, p, out));
   }
   void precon_rhs(const double* Q, const double* b, double bsc, double* rp, double* rl) {
+    if (general) {
+      tally(LC_RHS, 2 * bQ() + bP() + bL());
+      HDG_DISPATCH(k_g_precon<KK><<<(ggeo.nc + 63) / 64, 64, 0, stream>>>(ggeo, Q, b, bsc, rp));
+      csr(gd.Rb, b, bsc, 0.0, rl);
+      return;
+    }
     halo_Q(Q);
     halo_Q(b);
     HIPCHECK(hipMemsetAsync(rl, 0, sizeof(double) * NLv, stream));
@@ -1199,15 +1368,16 @@ struct Engine {
     tally(LC_RHS, 2 * bQ() + bP() + bL());
     HDG_DISPATCH(k_precon_rhs<KK><<<cell_grid(), bs(), 0, stream>>>(g, dt, Q, b, bsc, rp, rl));
   }
-  void q_to_modal(const double* nodal, double* modal) { HDG_DISPATCH(k_q_nodal_to_modal<KK><<<cell_grid(), bs(), 0, stream>>>(g, dt, nodal, modal)); }
-  void q_to_nodal(const double* modal, double* nodal) { HDG_DISPATCH(k_q_modal_to_nodal<KK><<<cell_grid(), bs(), 0, stream>>>(g, dt, modal, nodal)); }
-  void p_to_modal(const double* nodal, double* modal) { HDG_DISPATCH(k_p_nodal_to_modal<KK><<<cell_grid(), bs(), 0, stream>>>(g, dt, nodal, modal)); }
-  void p_to_nodal(const double* modal, double* nodal) { HDG_DISPATCH(k_p_modal_to_nodal<KK><<<cell_grid(), bs(), 0, stream>>>(g, dt, modal, nodal)); }
+  void q_to_modal(const double* nodal, double* modal) { if (general) { csr(gd.Cq, nodal, 1.0, 0.0, modal); return; } HDG_DISPATCH(k_q_nodal_to_modal<KK><<<cell_grid(), bs(), 0, stream>>>(g, dt, nodal, modal)); }
+  void q_to_nodal(const double* modal, double* nodal) { if (general) { csr(gd.Cqi, modal, 1.0, 0.0, nodal); return; } HDG_DISPATCH(k_q_modal_to_nodal<KK><<<cell_grid(), bs(), 0, stream>>>(g, dt, modal, nodal)); }
+  void p_to_modal(const double* nodal, double* modal) { if (general) { csr(gd.Cp, nodal, 1.0, 0.0, modal); return; } HDG_DISPATCH(k_p_nodal_to_modal<KK><<<cell_grid(), bs(), 0, stream>>>(g, dt, nodal, modal)); }
+  void p_to_nodal(const double* modal, double* nodal) { if (general) { csr(gd.Cpi, modal, 1.0, 0.0, nodal); return; } HDG_DISPATCH(k_p_modal_to_nodal<KK><<<cell_grid(), bs(), 0, stream>>>(g, dt, modal, nodal)); }
   void l_to_modal(double* nodal, double* modal) {
+    if (general) { csr(gd.Cl, nodal, 1.0, 0.0, modal); return; }
     HIPCHECK(hipMemsetAsync(modal, 0, sizeof(double) * NLv, stream));
     HDG_DISPATCH(k_l_convert<KK, true><<<corner_grid_all(), bs(), 0, stream>>>(g_all, dt, nodal, modal));
   }
-  void l_to_nodal(double* modal, double* nodal) { HDG_DISPATCH(k_l_convert<KK, false><<<corner_grid_all(), bs(), 0, stream>>>(g_all, dt, nodal, modal)); }
+  void l_to_nodal(double* modal, double* nodal) { if (general) { csr(gd.Cli, modal, 1.0, 0.0, nodal); return; } HDG_DISPATCH(k_l_convert<KK, false><<<corner_grid_all(), bs(), 0, stream>>>(g_all, dt, nodal, modal)); }
 
   // ------------------------------------------------------------------ vector helpers
   // (whole arrays, ghost rows included: a result is valid on the ghost rows all its inputs are valid on -- fl)
@@ -1268,6 +1438,7 @@ struct Engine {
   // a row of a plane holds 2 nx doubles)
   enum { KC = 1, KL = 2, KQ = 3 };
   RowMask mask_for(int kind) const {
+    if (general) return RowMask{0, 1, 0, 0};  // a single rank owns every entry
     if (kind == KL) return RowMask{g.P, g.ny + 2 * GH, GH, GH + g.nyc - 1};
     if (kind == KQ) return RowMask{2 * g.nx, g.R, GH, GH + g.ny - 1};
     return RowMask{g.nx, g.R, GH, GH + g.ny - 1};
@@ -1318,6 +1489,12 @@ struct Engine {
   }
   // ------------------------------------------------------------------ pressure mean shift
   void shift(double* p, double* l) {
+    if (general) {  // p_mean = int p / vol (common.py:72-73, hdg_imex.py:471-478); the constant 1 in the modal bases
+      const double pm = dot(NPv, p, d_int_p, KC) / gm->volume;
+      axpby(NPv, -pm, d_one_p, 1.0, p);
+      if (l) axpby(NLv, -pm, d_one_l, 1.0, l);
+      return;
+    }
     const double c0 = g.h / std::sqrt(2.0);  // integral of the mode-0 basis function = its "1" coefficient
     const double vol = Ldom * Ldom;          // domain_volume (common.py:72-73)
     int nb = std::min(dot_blocks, vec_blocks(g.Nc));
@@ -1381,6 +1558,12 @@ struct Engine {
 
   // ------------------------------------------------------------------ tentative velocity solve
   void ensure_dinv(int idx, double gamma) {
+    if (general) {
+      if (dinv_gamma[idx] == gamma && gdinv[(size_t)idx].nrows) return;
+      gdinv[(size_t)idx] = upload_csr(assemble_block_jacobi(*gtab, *gm, gloc, gamma));
+      dinv_gamma[idx] = gamma;
+      return;
+    }
     if (dinv_gamma[idx] == gamma && dinv0[idx]) return;
     dvec a = tab->blockJacobiInverse(0, gamma), b = tab->blockJacobiInverse(1, gamma);
     if (!dinv0[idx]) { dinv0[idx] = dalloc((long)a.size()); dinv1[idx] = dalloc((long)b.size()); }
@@ -1421,6 +1604,7 @@ struct Engine {
   }
   // z = M r  (tentative-velocity preconditioner)
   void tent_precond(int didx, const double* r, double* z) {
+    if (general) { csr(gdinv[(size_t)didx], r, 1.0, 0.0, z); return; }
     if (cfg.tent_precond == 0) {
       blockdiag(dinv0[didx], dinv1[didx], r, nullptr, 0.0, z);
     } else if (cfg.tent_precond == 1) {
@@ -2582,6 +2766,7 @@ struct Engine {
          *cg_dinv = nullptr, *uproj = nullptr;
   int cg_its_last = 0;
   void cg_setup() {
+    if (general) general_unsupported("the continuous space (tracer, vorticity)");
     if (cg_ready) return;
     if (comm->size > 1) throw std::string("the continuous space (tracer, vorticity) is implemented for a single rank");
     const int p = K + 1;
@@ -2821,6 +3006,7 @@ struct Engine {
 
   // ------------------------------------------------------------------ host <-> device fields
   long n_edges() const {
+    if (general) return gm->ne;
     if (periodic) return 3L * g.nx * g.ny;
     return (long)g.nx * (g.ny + 1) + (long)(g.nx + 1) * g.ny + (long)g.nx * g.ny;
   }
@@ -2859,6 +3045,11 @@ struct Engine {
 
   // physical coordinates of the velocity / pressure nodes in boundary (reference) numbering
   void node_coords(double* xq, double* xp) const {
+    if (general) {
+      if (xq) std::copy(gops.xq.begin(), gops.xq.end(), xq);
+      if (xp) std::copy(gops.xp.begin(), gops.xp.end(), xp);
+      return;
+    }
     for (int which = 0; which < 2; which++) {
       double* out = which == 0 ? xq : xp;
       if (!out) continue;
@@ -2889,6 +3080,7 @@ struct Engine {
   static constexpr int N_TIME_KERNELS = 15;
   double time_kernel(int kernel, int reps) {
     if (kernel < 0 || kernel >= N_TIME_KERNELS) throw std::string("unknown kernel id");  // before any state is touched
+    if (general) general_unsupported("hdg_time_kernel");
     // halo exchanges are switched off for the bare launches (the call is not collective); restored on EVERY exit path
     struct Guard {
       Engine& e;
@@ -3065,6 +3257,30 @@ static int create_impl(const hdg_config* cfg, int rank, int nranks, int backend,
   } catch (const std::exception& e) { g_create_error = e.what(); return HDG_ERR_ARG;
   } catch (...) { g_create_error = "unknown error"; return HDG_ERR_ARG; }
 }
+int hdg_create_general(const hdg_config* cfg, int n_vertices, const double* coords, int n_cells, const int* cells, hdg_handle** out) {
+  if (!cfg || !out || !coords || !cells) return HDG_ERR_ARG;
+  *out = nullptr;
+  try {
+    if (hipSetDevice(cfg->device) != hipSuccess) { g_create_error = "hipSetDevice failed (no GPU?)"; return HDG_ERR_HIP; }
+    std::unique_ptr<hdg::Comm> comm(new hdg::Comm());
+    hdg::Engine* e = new hdg::Engine(*cfg, comm.get(), n_vertices, coords, n_cells, cells);
+    comm.release();
+    *out = new hdg_handle{e, ""};
+    return HDG_OK;
+  } catch (const hdg::HipError& e) { g_create_error = e.msg; return HDG_ERR_HIP;
+  } catch (const hdg::CommError& e) { g_create_error = e.msg; return HDG_ERR_COMM;
+  } catch (const std::string& e) { g_create_error = e; return HDG_ERR_ARG;
+  } catch (const std::runtime_error& e) { g_create_error = e.what(); return HDG_ERR_SINGULAR;
+  } catch (const std::exception& e) { g_create_error = e.what(); return HDG_ERR_ARG;
+  } catch (...) { g_create_error = "unknown error"; return HDG_ERR_ARG; }
+}
+int hdg_general_topology(const hdg_handle* h, int* edge_vertices, int* edge_cells) {
+  if (!h || !h->eng || !h->eng->general) return HDG_ERR_ARG;
+  const hdg::GMesh& M = *h->eng->gm;
+  if (edge_vertices) std::copy(M.ev.begin(), M.ev.end(), edge_vertices);
+  if (edge_cells) std::copy(M.ecell.begin(), M.ecell.end(), edge_cells);
+  return HDG_OK;
+}
 int hdg_destroy(hdg_handle* h) {
   if (!h) return HDG_ERR_ARG;
   delete h->eng;
@@ -3076,7 +3292,7 @@ const char* hdg_last_error(const hdg_handle* h) { return h ? h->err.c_str() : g_
 int hdg_get_sizes(const hdg_handle* h, long* n_cells, long* n_edges, int* n_u, int* n_p, int* n_l) {
   if (!h || !h->eng) return HDG_ERR_ARG;
   const hdg::Engine& E = *h->eng;
-  if (n_cells) *n_cells = 2L * E.g.nx * E.g.ny;
+  if (n_cells) *n_cells = E.general ? (long)E.gm->nc : 2L * E.g.nx * E.g.ny;
   if (n_edges) *n_edges = E.n_edges();
   if (n_u) *n_u = E.NU;
   if (n_p) *n_p = E.NP;
@@ -3389,7 +3605,8 @@ int hdg_integrate_pressure(hdg_handle* h, const double* p, double* integral) {
   HDG_API_BEGIN(h)
   if (!p || !integral) throw std::string("null argument");
   E.put_P(p, E.wP1);
-  *integral = E.g.h / std::sqrt(2.0) * E.dot(E.g.Nc, E.wP1, E.ones_c, hdg::Engine::KC);
+  *integral = E.general ? E.dot(E.NPv, E.wP1, E.d_int_p, hdg::Engine::KC)
+                        : E.g.h / std::sqrt(2.0) * E.dot(E.g.Nc, E.wP1, E.ones_c, hdg::Engine::KC);
   HDG_API_END(h)
 }
 int hdg_time_kernel(hdg_handle* h, int kernel, int reps, double* ms_per_launch) {

@@ -1,0 +1,186 @@
+// Device side of the general-mesh path (hdg_general.hpp): one generic CSR kernel for every solution-independent operator
+// and the two solution-dependent forms with per-cell geometry.  Vector layouts: velocity (c * 2NU + d * NU + m), pressure
+// (c * NP + r), trace (e * NL + a): cell- / edge-major, modal, physically orthonormal bases.
+//
+// Bound: the CSR kernel reads 12 B of matrix per 2 flops -- it is matrix-bandwidth bound by construction (the price of
+// per-cell geometry without a per-shape table); the advection kernel reads its geometry (12 doubles + 9 ints per cell) and
+// shares the reference tabulations through the scalar / L1 path.  This path exists for the reference's unstructured
+// set-ups (UnitDiskMesh, a few 10^3 .. 10^5 cells), not for the headline benchmark.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace hdg {
+
+struct DevCsr {
+  int nrows = 0, ncols = 0;
+  long nnz = 0;
+  const int* rowptr = nullptr;
+  const int* col = nullptr;
+  const double* val = nullptr;
+};
+
+// y = beta * y + alpha * A x      (one thread per row; rows hold 10 .. 300 entries)
+__global__ void k_csr_apply(DevCsr A, const double* __restrict__ x, double alpha, double beta, double* __restrict__ y) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= A.nrows) return;
+  double acc = 0.0;
+  const int b = A.rowptr[r], e = A.rowptr[r + 1];
+  for (int q = b; q < e; q++) acc = fma(A.val[q], x[A.col[q]], acc);
+  y[r] = beta == 0.0 ? alpha * acc : fma(alpha, acc, beta * y[r]);
+}
+
+struct GGeo {
+  int nc;
+  const double* inv_sdet;  // nc: 1 / sqrt(detJ)  (scale of the orthonormal basis)
+  const double* detJ;      // nc
+  const double* Jinv;      // nc x 4 row-major: d xi_rho / d x_d = Jinv[rho * 2 + d]
+  const int* cnbr;         // nc x 3: neighbour across local edge l, -1 on the boundary
+  const int* ctab;         // nc x 3: own edge table  l * 2 + flip
+  const int* ntab;         // nc x 3: the neighbour's edge table for the same edge
+  const double* csig;      // nc x 3: +1 = the fixed edge normal points out of the cell
+  const double* celen;     // nc x 3
+  const double* cenx;      // nc x 3
+  const double* ceny;      // nc x 3
+  const double *cw, *cPhi, *cGxi, *cGeta;  // cell rule: weights (sum 1/2), nqc x NU tabulations on the reference element
+  const double *ew, *ePhi, *eGxi, *eGeta;  // edge rule on [0, 1]; [l * 2 + flip][nqe x NU]
+  int nqc, nqe;
+  double alpha;
+};
+
+// y = x - gamma F(Q*) x  (bsub != nullptr: bsub - that), F = f_impl of hdg_imex.py:313-331; the arithmetic of k_adv_apply
+// with the two shared shape tables replaced by (reference tabulation, per-cell Jacobian)
+template <int K>
+__global__ __launch_bounds__(64) void k_g_adv(GGeo G, const double* __restrict__ xin, const double* __restrict__ qstar,
+                                              double* __restrict__ out, double gamma, double upwind, const double* __restrict__ bsub) {
+  constexpr int NU = Dim<K>::NU, N2 = 2 * NU;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= G.nc) return;
+  double x[N2], qs[N2], F[N2];
+#pragma unroll
+  for (int n = 0; n < N2; n++) { x[n] = xin[(long)c * N2 + n]; qs[n] = qstar[(long)c * N2 + n]; F[n] = 0.0; }
+  const double s = G.inv_sdet[c], dj = G.detJ[c];
+  const double j00 = G.Jinv[4 * (long)c + 0] * s, j01 = G.Jinv[4 * (long)c + 1] * s, j10 = G.Jinv[4 * (long)c + 2] * s,
+               j11 = G.Jinv[4 * (long)c + 3] * s;
+  for (int q = 0; q < G.nqc; q++) {
+    double qx = 0, qy = 0, dxx = 0, dxy = 0, dyx = 0, dyy = 0;  // dab = d_b x_a
+    for (int m = 0; m < NU; m++) {
+      const double ph = G.cPhi[q * NU + m] * s, gxi = G.cGxi[q * NU + m], get = G.cGeta[q * NU + m];
+      const double gx = j00 * gxi + j10 * get, gy = j01 * gxi + j11 * get;
+      qx = fma(ph, qs[m], qx); qy = fma(ph, qs[NU + m], qy);
+      dxx = fma(gx, x[m], dxx); dxy = fma(gy, x[m], dxy);
+      dyx = fma(gx, x[NU + m], dyx); dyy = fma(gy, x[NU + m], dyy);
+    }
+    const double w = G.cw[q] * dj;
+    const double ax = -w * (qx * dxx + qy * dxy), ay = -w * (qx * dyx + qy * dyy);
+    for (int m = 0; m < NU; m++) {
+      const double ph = G.cPhi[q * NU + m] * s;
+      F[m] = fma(ph, ax, F[m]);
+      F[NU + m] = fma(ph, ay, F[NU + m]);
+    }
+  }
+  for (int l = 0; l < 3; l++) {
+    const int cn = G.cnbr[3 * (long)c + l];
+    const bool has = cn >= 0;
+    const double* __restrict__ Po = G.ePhi + (long)G.ctab[3 * (long)c + l] * G.nqe * NU;
+    const double* __restrict__ Pn = G.ePhi + (long)(has ? G.ntab[3 * (long)c + l] : 0) * G.nqe * NU;
+    const double sn = has ? G.inv_sdet[cn] : 0.0;
+    const double nx_ = G.cenx[3 * (long)c + l], ny_ = G.ceny[3 * (long)c + l], sg = G.csig[3 * (long)c + l];
+    const double len = G.celen[3 * (long)c + l], pen = G.alpha / len;
+    double xn[N2];
+#pragma unroll
+    for (int n = 0; n < N2; n++) xn[n] = has ? xin[(long)cn * N2 + n] : 0.0;
+    for (int q = 0; q < G.nqe; q++) {
+      double ox = 0, oy = 0, bx = 0, by = 0, qn = 0;
+      for (int m = 0; m < NU; m++) {
+        const double po = Po[q * NU + m] * s, pn = Pn[q * NU + m] * sn;
+        ox = fma(po, x[m], ox); oy = fma(po, x[NU + m], oy);
+        bx = fma(pn, xn[m], bx); by = fma(pn, xn[NU + m], by);
+        qn = fma(po, fma(nx_, qs[m], ny_ * qs[NU + m]), qn);
+      }
+      const double w = G.ew[q] * len;
+      const double cf = has ? w * (0.5 * sg * qn - upwind * fabs(qn)) : 0.0;
+      const double jx = ox - bx, jy = oy - by;
+      const double jn = (jx * nx_ + jy * ny_) * pen * w;
+      const double vx = cf * jx - jn * nx_, vy = cf * jy - jn * ny_;
+      for (int m = 0; m < NU; m++) {
+        const double po = Po[q * NU + m] * s;
+        F[m] = fma(po, vx, F[m]);
+        F[NU + m] = fma(po, vy, F[NU + m]);
+      }
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < N2; n++) {
+    const double v = fma(-gamma, F[n], x[n]);
+    out[(long)c * N2 + n] = bsub ? bsub[(long)c * N2 + n] - v : v;
+  }
+}
+
+// v = -b + (Q.grad) Q at one point from tabulated values / reference gradients of one cell
+template <int NU>
+__device__ __forceinline__ void g_point_v(const double* __restrict__ Ph, const double* __restrict__ Gxi, const double* __restrict__ Geta,
+                                          int q, double s, double j00, double j01, double j10, double j11, const double* x,
+                                          const double* b, double& vx, double& vy) {
+  double qx = 0, qy = 0, bx = 0, by = 0, dxx = 0, dxy = 0, dyx = 0, dyy = 0;
+  for (int m = 0; m < NU; m++) {
+    const double ph = Ph[q * NU + m] * s, gxi = Gxi[q * NU + m], get = Geta[q * NU + m];
+    const double gx = j00 * gxi + j10 * get, gy = j01 * gxi + j11 * get;
+    qx = fma(ph, x[m], qx); qy = fma(ph, x[NU + m], qy);
+    bx = fma(ph, b[m], bx); by = fma(ph, b[NU + m], by);
+    dxx = fma(gx, x[m], dxx); dxy = fma(gy, x[m], dxy);
+    dyx = fma(gx, x[NU + m], dyx); dyy = fma(gy, x[NU + m], dyy);
+  }
+  vx = -bx + qx * dxx + qy * dxy;
+  vy = -by + qx * dyx + qy * dyy;
+}
+
+// cell part of the pressure-reconstruction right-hand side (hdg_imex.py:201-207):
+//   rp = weak_divergence(psi, v),  v = -bscale * b + (Q.grad) Q   (per cell: -(grad psi, v)_K + <psi, {{v}}.n>_int)
+template <int K>
+__global__ __launch_bounds__(64) void k_g_precon(GGeo G, const double* __restrict__ Q, const double* __restrict__ bnew, double bscale,
+                                                 double* __restrict__ rp) {
+  constexpr int NU = Dim<K>::NU, NP = Dim<K>::NP, N2 = 2 * NU;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= G.nc) return;
+  double x[N2], b[N2], y[NP];
+#pragma unroll
+  for (int n = 0; n < N2; n++) { x[n] = Q[(long)c * N2 + n]; b[n] = bscale * bnew[(long)c * N2 + n]; }
+#pragma unroll
+  for (int r = 0; r < NP; r++) y[r] = 0.0;
+  const double s = G.inv_sdet[c], dj = G.detJ[c];
+  const double j00 = G.Jinv[4 * (long)c + 0] * s, j01 = G.Jinv[4 * (long)c + 1] * s, j10 = G.Jinv[4 * (long)c + 2] * s,
+               j11 = G.Jinv[4 * (long)c + 3] * s;
+  for (int q = 0; q < G.nqc; q++) {
+    double vx, vy;
+    g_point_v<NU>(G.cPhi, G.cGxi, G.cGeta, q, s, j00, j01, j10, j11, x, b, vx, vy);
+    const double w = G.cw[q] * dj;
+    for (int r = 0; r < NP; r++) {
+      const double gxi = G.cGxi[q * NU + r], get = G.cGeta[q * NU + r];
+      y[r] -= w * ((j00 * gxi + j10 * get) * vx + (j01 * gxi + j11 * get) * vy);
+    }
+  }
+  for (int l = 0; l < 3; l++) {
+    const int cn = G.cnbr[3 * (long)c + l];
+    if (cn < 0) continue;
+    const long to = (long)G.ctab[3 * (long)c + l] * G.nqe * NU, tn = (long)G.ntab[3 * (long)c + l] * G.nqe * NU;
+    const double sn = G.inv_sdet[cn];
+    const double n00 = G.Jinv[4 * (long)cn + 0] * sn, n01 = G.Jinv[4 * (long)cn + 1] * sn, n10 = G.Jinv[4 * (long)cn + 2] * sn,
+                 n11 = G.Jinv[4 * (long)cn + 3] * sn;
+    const double nx_ = G.cenx[3 * (long)c + l], ny_ = G.ceny[3 * (long)c + l], sg = G.csig[3 * (long)c + l], len = G.celen[3 * (long)c + l];
+    double xn[N2], bn[N2];
+#pragma unroll
+    for (int n = 0; n < N2; n++) { xn[n] = Q[(long)cn * N2 + n]; bn[n] = bscale * bnew[(long)cn * N2 + n]; }
+    for (int q = 0; q < G.nqe; q++) {
+      double ox, oy, px, py;
+      g_point_v<NU>(G.ePhi + to, G.eGxi + to, G.eGeta + to, q, s, j00, j01, j10, j11, x, b, ox, oy);
+      g_point_v<NU>(G.ePhi + tn, G.eGxi + tn, G.eGeta + tn, q, sn, n00, n01, n10, n11, xn, bn, px, py);
+      const double vn = 0.5 * ((ox + px) * nx_ + (oy + py) * ny_);
+      const double w = G.ew[q] * len * sg * vn;
+      for (int r = 0; r < NP; r++) y[r] = fma(G.ePhi[to + q * NU + r] * s, w, y[r]);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < NP; r++) rp[(long)c * NP + r] = y[r];
+}
+
+}  // namespace hdg

@@ -2,10 +2,10 @@
 
     python -m incompressibleeulerhdg_amd.driver --nx 64 --degree 2 --use_projection_method
 
-``--problem taylorgreen`` (unit square) and ``--problem shear`` (doubly periodic square, driver.py:182-183) are built;
-``kelvinhelmholtz`` needs the unstructured disk mesh and raises, as do the ``conforming`` / ``dg`` discretisations
-(SURVEY.md section 2.1).  ``--animation`` (evolution.pvd with the CG vorticity, callbacks.py:30-85) and
-``--tracer_advection`` (driver.py:340-344) work on both meshes.  The final fields are written to ``solution.pvd``
+``--problem taylorgreen`` (unit square), ``--problem shear`` (doubly periodic square, driver.py:182-183) and
+``--problem kelvinhelmholtz`` (UnitDiskMesh(refinement), driver.py:184-185: the general-mesh path, projection method only)
+are built; the ``conforming`` / ``dg`` discretisations raise.  ``--animation`` (evolution.pvd with
+the CG vorticity, callbacks.py:30-85) and ``--tracer_advection`` (driver.py:340-344) work on the two square meshes.  The final fields are written to ``solution.pvd``
 (``--output``) like the reference does (driver.py:356-385).
 """
 import argparse
@@ -16,8 +16,8 @@ import numpy as np
 
 from .auxilliary.callbacks import AnimationCallback
 from .auxilliary.logging import log_summary
-from .mesh import Function, PeriodicSquareMesh, UnitSquareMesh
-from .model_problems import DoubleLayerShearFlow, TaylorGreen
+from .mesh import Function, PeriodicSquareMesh, UnitDiskMesh, UnitSquareMesh
+from .model_problems import DoubleLayerShearFlow, KelvinHelmholtz, TaylorGreen
 from .output import VTKFile
 from .timesteppers import (
     IncompressibleEulerHDGIMEXARS2_232,
@@ -68,13 +68,17 @@ def build_parser():
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
-    if args.problem == "kelvinhelmholtz":
-        raise RuntimeError("problem 'kelvinhelmholtz' needs the unstructured disk mesh (driver.py:184-185): not implemented")
     if args.discretisation != "hdg":
         raise RuntimeError(f"discretisation '{args.discretisation}' is out of scope of the MI355X hot path")
     callbacks = [AnimationCallback("evolution.pvd")] if args.animation else None  # driver.py:187
     if args.problem == "shear":
         mesh = PeriodicSquareMesh(args.nx, args.nx, L=2 * np.pi, quadrilateral=False)  # driver.py:182-183
+    elif args.problem == "kelvinhelmholtz":
+        mesh = UnitDiskMesh(refinement_level=args.refinement)  # driver.py:184-185
+        if args.timestepper == "implicit" and not args.use_projection_method:
+            raise RuntimeError("general meshes: the projection method only (add --use_projection_method)")
+        if not args.use_projection_method:
+            raise RuntimeError("general meshes: the projection method only (add --use_projection_method)")
     else:
         mesh = UnitSquareMesh(args.nx, args.nx, quadrilateral=False)  # driver.py:181
     if args.timestepper == "implicit":
@@ -93,7 +97,10 @@ def main(argv=None):
     print("+-------------------------------------------------+")
     print()
     print(f"model problem = {args.problem}")
-    print(f"mesh size = {args.nx} x {args.nx}")
+    if args.problem == "kelvinhelmholtz":
+        print(f"refinement level = {args.refinement}")
+    else:
+        print(f"mesh size = {args.nx} x {args.nx}")
     print(f"forcing = {args.forcing}")
     print(f"kappa = {args.kappa}")
     print(f"polynomial degree = {args.degree}")
@@ -137,6 +144,8 @@ def main(argv=None):
         print()
     if args.problem == "shear":
         model_problem = DoubleLayerShearFlow(timestepper._V_Q, timestepper._V_p)  # driver.py:334-335
+    elif args.problem == "kelvinhelmholtz":
+        model_problem = KelvinHelmholtz(timestepper._V_Q, timestepper._V_p)  # driver.py:336-337
     else:
         model_problem = TaylorGreen(timestepper._V_Q, timestepper._V_p, args.forcing, args.kappa)
     Q_0, p_0 = model_problem.initial_condition()
@@ -145,8 +154,8 @@ def main(argv=None):
     kw = {"fused": True} if (args.fused and args.timestepper != "implicit") else {}
     Q, p = timestepper.solve(Q_0, p_0, q_0, model_problem.f_rhs(), args.tfinal, warmup=args.warmup, **kw)
     log_summary()
-    if args.problem == "shear":
-        # no exact solution (the reference's driver calls model_problem.solution, which this problem lacks: it stops here
+    if args.problem in ("shear", "kelvinhelmholtz"):
+        # no exact solution (the reference's driver calls model_problem.solution, which these problems lack: it stops here
         # with an AttributeError); write the final fields
         if args.output:
             Q.rename("velocity")

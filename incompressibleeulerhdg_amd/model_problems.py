@@ -1,14 +1,14 @@
 """Model problems as node-evaluated arrays (reference: src/model_problems.py:10-105).
 
-The manufactured Taylor-Green vortex (model_problems.py:38-105) and the double-layer shear flow on the periodic
-square (:134-196); the Kelvin-Helmholtz problem needs the unstructured disk mesh and is out of scope.
+The manufactured Taylor-Green vortex (model_problems.py:38-105), the Kelvin-Helmholtz instability on the unit disk
+(:108-131) and the double-layer shear flow on the periodic square (:134-196).
 """
 
 import numpy as np
 
 from .mesh import Function
 
-__all__ = ["TaylorGreen", "DoubleLayerShearFlow", "SeparableForcing"]
+__all__ = ["TaylorGreen", "KelvinHelmholtz", "DoubleLayerShearFlow", "SeparableForcing"]
 
 
 class SeparableForcing:
@@ -66,6 +66,28 @@ class TaylorGreen:
         if integrate_pressure is not None:
             p = p - integrate_pressure(p)  # model_problems.py:104: no division by the volume
         return Function(self.V_Q, Q, "velocity_exact"), Function(self.V_p, p, "pressure_exact")
+
+
+class KelvinHelmholtz:
+    """Kelvin-Helmholtz instability on the circular mesh (model_problems.py:108-131): rigid rotation (-y, x) inside
+    r < r_max = 0.5, fluid at rest outside, zero pressure, zero forcing; no exact solution."""
+
+    def __init__(self, V_Q, V_p, r_max=0.5):
+        self.V_Q, self.V_p = V_Q, V_p
+        self.r_max = r_max
+        inside = lambda x, y: x ** 2 + y ** 2 < r_max ** 2  # conditional(x**2 + y**2 < r_max**2, (-y, x), (0, 0))
+        self.Q_stationary = lambda x, y: (np.where(inside(x, y), -y, 0.0), np.where(inside(x, y), x, 0.0))
+        self.p_stationary = lambda x, y: 0.0 * x
+
+    def initial_condition(self):
+        return self.Q_stationary, self.p_stationary
+
+    def f_rhs(self):
+        """Zero forcing (model_problems.py:129-131)."""
+        return None
+
+    def solution(self, t, integrate_pressure=None):
+        return None
 
 
 class DoubleLayerShearFlow:

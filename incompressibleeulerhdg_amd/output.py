@@ -35,16 +35,30 @@ def _cell_vertices(nx, ny, L=1.0):
     return out
 
 
+def _mesh_cell_vertices(mesh):
+    """(ncells, 3, 2) vertex coordinates: structured numbering, or the cells of a general triangulation as given"""
+    if getattr(mesh, "general", False):
+        return np.asarray(mesh.vertices, dtype=float)[np.asarray(mesh.cells)]
+    return _cell_vertices(mesh.nx, mesh.ny, getattr(mesh, "L", 1.0))
+
+
 def cell_vertex_nodes(space):
-    """Indices (2, 3) of the three vertex nodes inside a cell's node list, per triangle shape."""
+    """Indices (2, 3) of the three vertex nodes inside a cell's node list, per triangle shape (general triangulations: every
+    cell carries the same node lattice on its own vertices, so the two rows coincide)."""
     mesh = space.mesh()
     ncells = mesh.num_cells()
     X = np.asarray(space.coordinates).reshape(ncells, -1, 2)
-    verts = _cell_vertices(mesh.nx, mesh.ny, getattr(mesh, "L", 1.0))
-    tol = 1e-9 * getattr(mesh, "L", 1.0) / max(mesh.nx, mesh.ny)
+    verts = _mesh_cell_vertices(mesh)
+    if getattr(mesh, "general", False):
+        tol = 1e-9 * np.sqrt(mesh.volume)
+    else:
+        tol = 1e-9 * getattr(mesh, "L", 1.0) / max(mesh.nx, mesh.ny)
     idx = np.empty((2, 3), dtype=int)
     for s in range(2):
         for v in range(3):
+            if s >= ncells:  # a one-cell mesh
+                idx[s, v] = idx[0, v]
+                continue
             d = np.max(np.abs(X[s] - verts[s, v]), axis=1)
             hit = np.nonzero(d < tol)[0]
             if hit.size != 1:
@@ -89,7 +103,7 @@ class VTKFile:
         mesh = functions[0].function_space().mesh()
         ncells = mesh.num_cells()
         pts = np.zeros((ncells * 3, 3), dtype="<f8")
-        pts[:, :2] = _cell_vertices(mesh.nx, mesh.ny, getattr(mesh, "L", 1.0)).reshape(-1, 2)
+        pts[:, :2] = _mesh_cell_vertices(mesh).reshape(-1, 2)
         conn = np.arange(ncells * 3, dtype="<i4")
         offs = np.arange(3, 3 * ncells + 1, 3, dtype="<i4")
         types = np.full(ncells, 5, dtype="<u1")  # VTK_TRIANGLE

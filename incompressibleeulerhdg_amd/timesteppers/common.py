@@ -28,12 +28,17 @@ class IncompressibleEuler(ABC):
         self._label = label
         self._engine_options = engine_options
         self._engine = None
-        self.domain_volume = float(getattr(mesh, "L", 1.0)) ** 2  # common.py:72-73
+        # common.py:72-73
+        self.domain_volume = float(mesh.volume) if getattr(mesh, "general", False) else float(getattr(mesh, "L", 1.0)) ** 2
 
     # -- engine and function spaces ------------------------------------------------------------
     def _create_engine(self, **kw):
-        opts = dict(nx=self._mesh.nx, ny=self._mesh.ny, degree=self.degree, dt=self._dt,
-                    periodic=getattr(self._mesh, "periodic", False), length=getattr(self._mesh, "L", 1.0))
+        if getattr(self._mesh, "general", False):
+            # general affine triangulation: per-element geometry (hdg_create_general)
+            opts = dict(vertices=self._mesh.vertices, cells=self._mesh.cells, degree=self.degree, dt=self._dt)
+        else:
+            opts = dict(nx=self._mesh.nx, ny=self._mesh.ny, degree=self.degree, dt=self._dt,
+                        periodic=getattr(self._mesh, "periodic", False), length=getattr(self._mesh, "L", 1.0))
         opts.update(kw)
         opts.update(self._engine_options)
         self._engine = Engine(**opts)

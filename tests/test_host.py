@@ -268,3 +268,28 @@ def test_bench_watchdog_ends_an_overrunning_phase():
     r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
     assert r.returncode == 4, (r.returncode, r.stderr.decode()[-500:])
     assert "stuck collective" in r.stderr.decode()
+
+
+def test_unit_disk_mesh_and_general_mesh_output(tmp_path):
+    """Product-side UnitDiskMesh (driver.py:184-185) and the VTK writer on a general triangulation (host side only)."""
+    from incompressibleeulerhdg_amd.mesh import Function, FunctionSpace, TriangleMesh, UnitDiskMesh
+    from incompressibleeulerhdg_amd.output import VTKFile, cell_vertex_nodes
+
+    for level in (0, 1, 2):
+        m = UnitDiskMesh(level)
+        assert m.num_cells() == 8 * 4 ** level and 2.8 < m.volume < np.pi
+        r = np.linalg.norm(m.vertices, axis=1)
+        assert r.max() < 1.0 + 1e-14 and np.sum(np.abs(r - 1.0) < 1e-13) == 8 * 2 ** level  # boundary vertices on the unit circle
+    with pytest.raises(ValueError):
+        TriangleMesh([[0, 0], [1, 0], [2, 0]], [[0, 1, 2]])
+    m = UnitDiskMesh(1)
+    # degree-2 lattice nodes (b outer, a inner) of every cell on its own vertices
+    lat = [(a / 2.0, b / 2.0) for b in range(3) for a in range(3 - b)]
+    v = m.vertices[m.cells]
+    X = np.stack([v[:, 0] + (v[:, 1] - v[:, 0]) * xi + (v[:, 2] - v[:, 0]) * eta for xi, eta in lat], axis=1).reshape(-1, 2)
+    V = FunctionSpace(m, "DG", 2, X)
+    assert np.array_equal(cell_vertex_nodes(V), [[0, 2, 5], [0, 2, 5]])
+    f = Function(V, X[:, 0] + 2 * X[:, 1], "f")
+    vtu = VTKFile(str(tmp_path / "disk.pvd")).write(f)
+    txt = open(vtu).read()
+    assert f'NumberOfCells="{m.num_cells()}"' in txt and 'Name="f"' in txt
