@@ -68,6 +68,14 @@ def _p(a):
     return None if a is None else a.ctypes.data_as(_dp)
 
 
+def stream_triad_gbs(n=1 << 26, reps=5):
+    """GB/s of an OpenMP stream triad on the twin's threads: the host memory bandwidth beside the CPU baseline."""
+    lib = load()
+    lib.hdgcpu_stream_triad_gbs.restype = C.c_double
+    lib.hdgcpu_stream_triad_gbs.argtypes = [C.c_long, C.c_int]
+    return float(lib.hdgcpu_stream_triad_gbs(n, reps))
+
+
 class CpuTwin:
     """Same keyword arguments as incompressibleeulerhdg_amd._lib.Engine (the hdg_config fields)."""
 

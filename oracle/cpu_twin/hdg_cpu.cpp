@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -134,6 +135,14 @@ struct Twin {
   // ------------------------------------------------------------------ K1: edge lift (BDM projection and relatives)
   // out_K = in_K + sum_e Out_e w (N'_e in_K' - N_e in_K),  w = 1/2 interior, boundary: -Out_e N_e in_K  (common.py:91-108)
   void lift(const vec& in, vec& out, const dvec* Out0, const dvec* Out1, bool packed3) const {
+    if (use_simd()) {
+      switch (K) {
+        case 1: lift_simd<1>(in, out, Out0, Out1, packed3); return;
+        case 2: lift_simd<2>(in, out, Out0, Out1, packed3); return;
+        case 3: lift_simd<3>(in, out, Out0, Out1, packed3); return;
+        default: lift_simd<4>(in, out, Out0, Out1, packed3); return;
+      }
+    }
 #pragma omp parallel for schedule(static)
     for (int j = 0; j < ny; j++)
       for (int i = 0; i < nx; i++)
@@ -157,11 +166,152 @@ struct Twin {
           for (int n = 0; n < N2; n++) out[c * N2 + n] = y[n];
         }
   }
+  // ---- SIMD forms of the two kernels that dominate a step (round 3: "a CPU baseline worth the name").  W consecutive cells
+  // of one shape and mesh row are processed together in a lane-blocked structure-of-arrays tile x[n][lane]: the shared
+  // operator tables become broadcast scalars and every inner loop runs over the W lanes (#pragma omp simd, AVX-512: one
+  // instruction per 8 cells).  Same arithmetic per cell as lift() / adv(), in the same order.
+  static constexpr int W = 8;
+  template <int KK>
+  void lift_simd(const vec& in, vec& out, const dvec* Out0, const dvec* Out1, bool packed3) const {
+    constexpr int NU_ = (KK + 2) * (KK + 3) / 2, N2_ = 2 * NU_, NE_ = KK + 2;
+#pragma omp parallel for schedule(static)
+    for (int j = 0; j < ny; j++)
+      for (int sh = 0; sh < 2; sh++)
+        for (int i0 = 0; i0 < nx; i0 += W) {
+          const int w = std::min(W, nx - i0);
+          alignas(64) double x[N2_][W], y[N2_][W], xn[N2_][W], d[NE_][W], has[W];
+          for (int n = 0; n < N2_; n++)
+            for (int l = 0; l < W; l++) x[n][l] = l < w ? in[cid(sh, i0 + l, j) * N2_ + n] : 0.0;
+          for (int n = 0; n < N2_; n++)
+#pragma omp simd
+            for (int l = 0; l < W; l++) y[n][l] = x[n][l];
+          for (int e = 0; e < 3; e++) {
+            for (int l = 0; l < W; l++) {
+              const long cn = l < w ? nbr(sh, e, i0 + l, j) : -1;
+              has[l] = cn >= 0 ? 1.0 : 0.0;
+              for (int n = 0; n < N2_; n++) xn[n][l] = cn >= 0 ? in[cn * N2_ + n] : 0.0;
+            }
+            const double *No = T->N[sh][e].data(), *Nn = T->N[1 - sh][e].data();
+            for (int a = 0; a < NE_; a++) {
+              alignas(64) double acc[W] = {0};
+              for (int n = 0; n < N2_; n++) {
+                const double no = No[a * N2_ + n], nn = Nn[a * N2_ + n];
+#pragma omp simd
+                for (int l = 0; l < W; l++) acc[l] += nn * xn[n][l] - no * x[n][l];
+              }
+#pragma omp simd
+              for (int l = 0; l < W; l++) d[a][l] = acc[l] * (has[l] != 0.0 ? 0.5 : 1.0);
+            }
+            const dvec* O = sh == 0 ? Out0 : Out1;
+            const double* Om = packed3 ? O->data() + (size_t)e * N2_ * NE_ : O[e].data();
+            for (int n = 0; n < N2_; n++)
+              for (int a = 0; a < NE_; a++) {
+                const double o = Om[n * NE_ + a];
+#pragma omp simd
+                for (int l = 0; l < W; l++) y[n][l] += o * d[a][l];
+              }
+          }
+          for (int l = 0; l < w; l++) {
+            double* dst = &out[cid(sh, i0 + l, j) * N2_];
+            for (int n = 0; n < N2_; n++) dst[n] = y[n][l];
+          }
+        }
+  }
+  template <int KK>
+  void adv_simd(const vec& xin, const vec& qstar, vec& out, double gamma, const vec* bsub) const {
+    constexpr int NU_ = (KK + 2) * (KK + 3) / 2, N2_ = 2 * NU_;
+    const double up = cfg.flux_upwind ? 1.0 : 0.0;
+    const int nqc = T->nqc, nqe = T->nqe;
+#pragma omp parallel for schedule(static)
+    for (int j = 0; j < ny; j++)
+      for (int sh = 0; sh < 2; sh++)
+        for (int i0 = 0; i0 < nx; i0 += W) {
+          const int w = std::min(W, nx - i0);
+          alignas(64) double x[N2_][W], qs[N2_][W], F[N2_][W], xn[N2_][W], has[W];
+          for (int n = 0; n < N2_; n++)
+            for (int l = 0; l < W; l++) {
+              const long c = l < w ? cid(sh, i0 + l, j) : cid(sh, i0, j);
+              x[n][l] = l < w ? xin[c * N2_ + n] : 0.0;
+              qs[n][l] = l < w ? qstar[c * N2_ + n] : 0.0;
+              F[n][l] = 0.0;
+            }
+          const double *Phi = T->cPhi[sh].data(), *Gx = T->cGx[sh].data(), *Gy = T->cGy[sh].data();
+          for (int q = 0; q < nqc; q++) {
+            alignas(64) double qx[W] = {0}, qy[W] = {0}, dxx[W] = {0}, dxy[W] = {0}, dyx[W] = {0}, dyy[W] = {0}, ax[W], ay[W];
+            for (int m = 0; m < NU_; m++) {
+              const double ph = Phi[q * NU_ + m], gx = Gx[q * NU_ + m], gy = Gy[q * NU_ + m];
+#pragma omp simd
+              for (int l = 0; l < W; l++) {
+                qx[l] += ph * qs[m][l]; qy[l] += ph * qs[NU_ + m][l];
+                dxx[l] += gx * x[m][l]; dxy[l] += gy * x[m][l]; dyx[l] += gx * x[NU_ + m][l]; dyy[l] += gy * x[NU_ + m][l];
+              }
+            }
+            const double wq = T->cw[q];
+#pragma omp simd
+            for (int l = 0; l < W; l++) { ax[l] = -wq * (qx[l] * dxx[l] + qy[l] * dxy[l]); ay[l] = -wq * (qx[l] * dyx[l] + qy[l] * dyy[l]); }
+            for (int m = 0; m < NU_; m++) {
+              const double ph = Phi[q * NU_ + m];
+#pragma omp simd
+              for (int l = 0; l < W; l++) { F[m][l] += ph * ax[l]; F[NU_ + m][l] += ph * ay[l]; }
+            }
+          }
+          for (int e = 0; e < 3; e++) {
+            for (int l = 0; l < W; l++) {
+              const long cn = l < w ? nbr(sh, e, i0 + l, j) : -1;
+              has[l] = cn >= 0 ? 1.0 : 0.0;
+              for (int n = 0; n < N2_; n++) xn[n][l] = cn >= 0 ? xin[cn * N2_ + n] : 0.0;
+            }
+            const double *Po = T->ePhi[sh][e].data(), *Pn = T->ePhi[1 - sh][e].data();
+            const double nx_ = T->enx[e], ny_ = T->eny[e], sg = T->sig[sh][e], pen = T->alpha / T->elen[e];
+            for (int q = 0; q < nqe; q++) {
+              alignas(64) double ox[W] = {0}, oy[W] = {0}, bx[W] = {0}, by[W] = {0}, qn[W] = {0}, vx[W], vy[W];
+              for (int m = 0; m < NU_; m++) {
+                const double po = Po[q * NU_ + m], pn = Pn[q * NU_ + m];
+#pragma omp simd
+                for (int l = 0; l < W; l++) {
+                  ox[l] += po * x[m][l]; oy[l] += po * x[NU_ + m][l];
+                  qn[l] += po * (nx_ * qs[m][l] + ny_ * qs[NU_ + m][l]);
+                  bx[l] += pn * xn[m][l]; by[l] += pn * xn[NU_ + m][l];
+                }
+              }
+              const double wq = T->ew[e][q];
+#pragma omp simd
+              for (int l = 0; l < W; l++) {
+                const double cf = has[l] * wq * (0.5 * sg * qn[l] - up * std::fabs(qn[l]));
+                const double jx = ox[l] - bx[l], jy = oy[l] - by[l];
+                const double jn = (jx * nx_ + jy * ny_) * pen * wq;
+                vx[l] = cf * jx - jn * nx_; vy[l] = cf * jy - jn * ny_;
+              }
+              for (int m = 0; m < NU_; m++) {
+                const double po = Po[q * NU_ + m];
+#pragma omp simd
+                for (int l = 0; l < W; l++) { F[m][l] += po * vx[l]; F[NU_ + m][l] += po * vy[l]; }
+              }
+            }
+          }
+          for (int l = 0; l < w; l++) {
+            const long c = cid(sh, i0 + l, j);
+            for (int n = 0; n < N2_; n++) {
+              const double v = x[n][l] - gamma * F[n][l];
+              out[c * N2_ + n] = bsub ? (*bsub)[c * N2_ + n] - v : v;
+            }
+          }
+        }
+  }
+  static bool use_simd() { static const bool off = std::getenv("HDG_CPU_NO_SIMD") != nullptr; return !off; }
   void bdm(const vec& in, vec& out) const { lift(in, out, T->Lift[0], T->Lift[1], false); }
 
   // ------------------------------------------------------------------ K3: advection operator (hdg_imex.py:313-331)
   //   out = x - gamma F(Q*) x   (bsub: out = bsub - (x - gamma F x))
   void adv(const vec& xin, const vec& qstar, vec& out, double gamma, const vec* bsub) const {
+    if (use_simd()) {
+      switch (K) {
+        case 1: adv_simd<1>(xin, qstar, out, gamma, bsub); return;
+        case 2: adv_simd<2>(xin, qstar, out, gamma, bsub); return;
+        case 3: adv_simd<3>(xin, qstar, out, gamma, bsub); return;
+        default: adv_simd<4>(xin, qstar, out, gamma, bsub); return;
+      }
+    }
     const double up = cfg.flux_upwind ? 1.0 : 0.0;
     const int nqc = T->nqc, nqe = T->nqe;
 #pragma omp parallel for schedule(static)
@@ -653,10 +803,30 @@ struct Twin {
       for (; j < m; j++) {
         adv(gmV[j], qstar, gt, gamma, nullptr);
         precond(gt, gw);
-        for (int l = 0; l <= j; l++) {
-          const double h = dotv(gw, gmV[l]);
-          H[(size_t)l * m + j] = h;
-          axpby(-h, gmV[l], 1.0, gw);
+        {
+          // classical Gram-Schmidt in two passes over memory (PETSc's default: VecMDot, then VecMAXPY), instead of the
+          // j + 1 dot / axpy pairs of the modified form: h_l = (w, V_l) in ONE pass, w -= sum h_l V_l in one more
+          const long nn = (long)gw.size();
+          double hh[64] = {0};
+          const int nl_ = j + 1;
+#pragma omp parallel
+          {
+            double loc[64] = {0};
+#pragma omp for schedule(static) nowait
+            for (long q = 0; q < nn; q++) {
+              const double wv = gw[q];
+              for (int l = 0; l < nl_; l++) loc[l] += wv * gmV[l][q];
+            }
+#pragma omp critical
+            for (int l = 0; l < nl_; l++) hh[l] += loc[l];
+          }
+          for (int l = 0; l < nl_; l++) H[(size_t)l * m + j] = hh[l];
+#pragma omp parallel for schedule(static)
+          for (long q = 0; q < nn; q++) {
+            double wv = gw[q];
+            for (int l = 0; l < nl_; l++) wv -= hh[l] * gmV[l][q];
+            gw[q] = wv;
+          }
         }
         const double hn = std::sqrt(dotv(gw, gw));
         H[(size_t)(j + 1) * m + j] = hn;
@@ -891,6 +1061,21 @@ int hdgcpu_destroy(Handle* h) { if (!h) return HDG_ERR_ARG; delete h->t; delete 
 const char* hdgcpu_last_error(const Handle* h) { return h ? h->err.c_str() : g_err.c_str(); }
 int hdgcpu_num_threads() { return omp_get_max_threads(); }
 void hdgcpu_set_num_threads(int n) { if (n > 0) omp_set_num_threads(n); }
+// host memory bandwidth the twin's threads reach (stream triad a = b + s c on n doubles, best of reps): GB/s, 24 B per entry
+double hdgcpu_stream_triad_gbs(long n, int reps) {
+  std::vector<double> a((size_t)n), b((size_t)n), c((size_t)n);
+#pragma omp parallel for schedule(static)
+  for (long i = 0; i < n; i++) { a[i] = 0.0; b[i] = 1.0 + 1e-9 * (double)i; c[i] = 2.0; }
+  double best = 0.0;
+  for (int r = 0; r < reps; r++) {
+    const double t0 = omp_get_wtime();
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < n; i++) a[i] = b[i] + 0.5 * c[i];
+    const double dt_ = omp_get_wtime() - t0;
+    if (dt_ > 0) best = std::max(best, 24.0 * (double)n / dt_ / 1e9);
+  }
+  return a[(size_t)(n / 2)] > 0 ? best : 0.0;
+}
 int hdgcpu_get_sizes(const Handle* h, long* n_cells, long* n_edges, int* n_u, int* n_p, int* n_l) {
   if (!h || !h->t) return HDG_ERR_ARG;
   *n_cells = h->t->ncell; *n_edges = h->t->nedge; *n_u = h->t->NU; *n_p = h->t->NP; *n_l = h->t->NL;
