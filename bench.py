@@ -51,8 +51,9 @@ def csrc_sha16():
 
     h = hashlib.sha256()
     d = os.path.join(ROOT, "incompressibleeulerhdg_amd", "csrc")
-    for f in ("hdg_kernels.hpp", "hdg_engine.hip", "hdg_tables.hpp", "hdg_comm.hpp"):
-        h.update(open(os.path.join(d, f), "rb").read())
+    for f in sorted(os.listdir(d)):  # every kernel / engine source
+        if f.endswith((".hpp", ".hip")):
+            h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
 
