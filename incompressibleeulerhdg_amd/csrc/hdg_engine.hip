@@ -30,6 +30,7 @@
 #include "hdg_comm.hpp"
 #include "hdg_kernels.hpp"
 #include "hdg_schur_mfma.hpp"
+#include "hdg_trace_tile.hpp"
 #include "hdg_cg.hpp"
 #include "hdg_tables.hpp"
 #include "hdg_general.hpp"
@@ -2204,13 +2205,49 @@ struct Engine {
     sweeps(nsw, true);
   }
   // z = M r for the condensed system
-  void trace_precond(const double* r, double* z) {
+  // LDS-tiled form of the two smoother applications (hdg_trace_tile.hpp): single rank, non-periodic structured mesh,
+  // two Chebyshev steps.  HDG_TRACE_NO_TILE: the five row-stencil launches of before.
+  bool use_trace_tile() const {
+    static const bool off = std::getenv("HDG_TRACE_NO_TILE") != nullptr;
+    static const int nsm = std::getenv("HDG_TRACE_SMOOTH_ITS") ? std::atoi(std::getenv("HDG_TRACE_SMOOTH_ITS")) : 2;
+    static const bool fuse = !std::getenv("HDG_TRACE_NO_FUSE");
+    // k = 4: the post kernel needs 274 VGPRs (15 trace values per corner and stage): 5.88 instead of 5.65 ms per solve at 512^2
+    return !off && fuse && nsm == 2 && cfg.trace_precond == 1 && comm->size == 1 && !periodic && !general && halo_on && K <= 3;
+  }
+  // returns true when w_out has received T z (the operator application the single-reduction CG needs next)
+  bool trace_precond(const double* r, double* z, double* w_out = nullptr) {
     if (cfg.trace_precond == 0) {
       zero(z, NLv);
       trace_cheb(r, ch_d, z, 0.0, 1.0);
-      return;
+      return false;
     }
     static const int nsm = std::getenv("HDG_TRACE_SMOOTH_ITS") ? std::atoi(std::getenv("HDG_TRACE_SMOOTH_ITS")) : 2;
+    if (use_trace_tile()) {
+      const double theta = 0.5 * (cheb_lmax + cheb_lmin), delta = 0.5 * (cheb_lmax - cheb_lmin), sigma1 = theta / delta;
+      const double rho = 1.0 / sigma1, rn = 1.0 / (2.0 * sigma1 - rho), c0 = 1.0 / theta, c1 = rn * rho, c2 = 2.0 * rn / delta;
+      const double nvtx = 8.0 * (g.nx + 1.0) * (g.ny + 1.0);
+      auto launch = [&](auto kk) {
+        constexpr int KK = decltype(kk)::value;
+        typedef TraceTile<KK> TT;
+        const dim3 grid((g.nx + 1 + TT::TW - 1) / TT::TW, (g.ny + 1 + TT::TH - 1) / TT::TH);
+        tally(LC_TRACE_SMOOTH, 3 * bL());
+        k_trace_pre_tile<KK><<<grid, TT::NTHREADS, 0, stream>>>(g, pdt(), r, c0, c1, c2, ch_d, wL2);
+        tally(LC_MG, bL() + nvtx);
+        k_trace_to_p1<<<corner_grid_all(), bs(), 0, stream>>>(g_all, NL, wL2, mg_b[0], dt.elen[0], dt.elen[2], dt.elen[1], 0);
+        run_vcycle();
+        tally(LC_TRACE_SMOOTH, (w_out ? 4 : 3) * bL() + nvtx);
+        k_trace_post_tile<KK><<<grid, TT::NTHREADS, 0, stream>>>(g, pdt(), ch_d, r, mg_x[0], std::sqrt(dt.elen[0]), std::sqrt(dt.elen[2]),
+                                                                 std::sqrt(dt.elen[1]), c0, c1, c2, z, w_out);
+      };
+      switch (K) {
+        case 1: launch(std::integral_constant<int, 1>{}); break;
+        case 2: launch(std::integral_constant<int, 2>{}); break;
+        case 3: launch(std::integral_constant<int, 3>{}); break;
+        default: launch(std::integral_constant<int, 4>{}); break;
+      }
+      fl.set(z, 0); fl.set(w_out, 0);
+      return w_out != nullptr;
+    }
     cheb_smooth(r, z, true, nsm);
     trace_apply(z, r, 1.0, -1.0, wL2, 0);  // restricted from owned rows only: no extension
     // restriction to the vertex grid from OWNED edges only (no halo of wL2): the cut rows are completed when the
@@ -2223,14 +2260,14 @@ struct Engine {
       k_p1p_to_trace<<<corner_grid(), bs(), 0, stream>>>(g, NL, mg_x[0], z, 1.0, dt.elen[0], dt.elen[2], dt.elen[1]);
       fl.set(z, 0);  // owned rows only: the wrapped ghost rows are stale
       cheb_smooth(r, z, false, nsm);
-      return;
+      return false;
     }
     tally(LC_MG, bL() + 8.0 * (g.nx + 1.0) * (g.ny + 1.0));
     k_trace_to_p1<<<corner_grid_all(), bs(), 0, stream>>>(g_all, NL, wL2, mg_b[0], dt.elen[0], dt.elen[2], dt.elen[1], partial);
     if (mg_distributed()) {
       vcycle_distributed_top();
       cheb_smooth(r, z, false, nsm, mg_x[0]);
-      return;
+      return false;
     }
     if (mg_gather) {
       // every rank contributes its (ny+1) vertex rows; one kernel assembles the global vector from the blocks
@@ -2242,6 +2279,7 @@ struct Engine {
     }
     run_vcycle();
     cheb_smooth(r, z, false, nsm, mg_x[0]);
+    return false;
   }
   void setup_trace_solver() {
     // null-space vector
@@ -2401,8 +2439,7 @@ struct Engine {
     double norm0 = -1.0;
     int its = 0;
     while (true) {
-      trace_precond(cg_r, cg_z);
-      trace_apply(cg_z, nullptr, 0.0, 1.0, cg_Ap);  // w = T z
+      if (!trace_precond(cg_r, cg_z, cg_Ap)) trace_apply(cg_z, nullptr, 0.0, 1.0, cg_Ap);  // w = T z
       multidot(NLv, cg_z, {tr_one, cg_r, cg_z, cg_Ap}, nullptr, KL, true);  // (z,n), (z,r), (z,z), (z,w), (n,r) -> d_res
       tally(LC_OTHER, 0.0);
       tally(LC_VEC, bL() * 11);  // k_cg_sr_update: reads z, n, w, p, s, x, r; writes p, s, x, r

@@ -1,0 +1,329 @@
+// The two smoother applications of the trace preconditioner (GTMG of hdg_imex.py:139-167: Chebyshev(2) + edge block-Jacobi
+// around the coarse-grid correction) as TWO kernels instead of five row-stencil launches per CG iteration:
+//
+//   k_trace_pre_tile   z = S_pre(r)            (zero start: d0 = Dinv r / theta, d1 = c1 d0 + c2 Dinv (r - T d0), z = d0 + d1)
+//                      res = r - T z           (what the restriction to the vertex grid consumes)
+//   k_trace_post_tile  z0 = z + P xc           (prolongation of the vertex-grid correction)
+//                      r0 = r - T z0, d0 = Dinv r0 / theta, z1 = z0 + d0
+//                      r1 = r0 - T d0, d1 = c1 d0 + c2 Dinv r1, z2 = z1 + d1
+//                      w  = T z2               (the operator application the single-reduction CG needs next)
+//
+// Why: each of the five stencil launches (k_trace_smooth x 3, k_trace_apply x 2) is bound by its own dependent-latency
+// chain (27 loads -> products -> block-Jacobi -> stores: 37-97 us for 150-390 MB at C3), not by bytes; folding pointwise
+// work into them bought 1-2 %.  Here a workgroup owns a tile of TW x TH grid corners, keeps the
+// stencil inputs of every stage in LDS with a halo that shrinks by one corner per operator application (2 for the pre
+// kernel, 3 for the post kernel: recomputed, not exchanged) and walks through the stages between barriers -- the scheme
+// of the vertex-grid kernels k_p1_down / k_p1_up.  Values a stage only needs pointwise (r, r0, z1) stay in registers: one
+// thread keeps the same corners through all stages (the index map of the halo-2 region; stages that act on a smaller region
+// mask the rest).
+//
+// Single rank, non-periodic meshes (physical boundaries only: a corner outside the mesh is a zero).  Same arithmetic per
+// corner as trace_stencil / k_trace_smooth.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace hdg {
+
+template <int K>
+struct TraceTile {
+  static constexpr int NL = Dim<K>::NL, NT = 3 * NL;
+  // Tile 16 x 8 corners, 256 threads: one corner of the halo-2 region (20 x 12 = 240) per thread.  Measured at C3 (k = 2),
+  // us per launch pre / post: 32 x 8 tiles with two corners per thread 93 / 148 (212 VGPRs in the post kernel), 32 x 8 with
+  // 512 threads 124 / 180, 16 x 8 87 / 135 (166 VGPRs, 3 workgroups per CU), 16 x 4 with 192 threads 103 / 166, 16 x 8 forced
+  // to 4 waves per SIMD 90 / 188 (spills).  The five row-stencil launches they replace: 60 + 37 and 97 + 78 + 37.
+  static constexpr int TW = 16, TH = 8, NTHREADS = 256;
+  static constexpr int W2 = TW + 4, H2 = TH + 4, N2 = W2 * H2;  // halo-2 region: the index map of every stage
+  static constexpr int W3 = TW + 6, H3 = TH + 6, N3 = W3 * H3;  // halo-3 region (post kernel, stage 0)
+  static constexpr int W1 = TW + 2, H1 = TH + 2, N1 = W1 * H1;  // halo-1 region
+  static constexpr int KMAX = (N2 + NTHREADS - 1) / NTHREADS;   // corners per thread
+};
+
+// (-S) v at the three edges of a corner from an LDS array A[(t * NL + m)][row][col] (region pitch RW, RH rows), corner at
+// (li, lj) of that region; own[] = the corner's own edges in local-edge order (H, D, V)
+template <int K, int RW, int RH>
+__device__ __forceinline__ void lds_trace_stencil(const double* __restrict__ A, int li, int lj, bool in_x, bool in_y, bool below,
+                                                  bool left, const DevTables& T, double* own, double* yH, double* yV, double* yD) {
+  constexpr int NL = Dim<K>::NL, NT = 3 * NL;
+  auto at = [&](int t, int m, int dj, int di) { return A[((t * NL + m) * RH + (lj + dj)) * RW + (li + di)]; };
+  double uA[NT], uB[NT], uC[NT];
+#pragma unroll
+  for (int m = 0; m < NL; m++) {
+    own[m] = at(0, m, 0, 0); own[NL + m] = at(2, m, 0, 0); own[2 * NL + m] = at(1, m, 0, 0);
+    uA[m] = at(0, m, 1, 0); uA[2 * NL + m] = at(1, m, 0, 1);         // U(i,j):   H(i,j+1), V(i+1,j)
+    uB[NL + m] = at(2, m, -1, 0); uB[2 * NL + m] = at(1, m, -1, 1);  // U(i,j-1): D(i,j-1), V(i+1,j-1)
+    uC[m] = at(0, m, 1, -1); uC[NL + m] = at(2, m, 0, -1);           // U(i-1,j): H(i-1,j+1), D(i-1,j)
+    yH[m] = yV[m] = yD[m] = 0.0;
+  }
+  const bool vL = in_x && in_y, vB = in_x && below, vW = in_y && left;
+#pragma unroll
+  for (int m = 0; m < NL; m++) {
+    if (!in_x) own[m] = 0.0;
+    if (!vL) own[NL + m] = 0.0;
+    if (!in_y) own[2 * NL + m] = 0.0;
+    uA[NL + m] = own[NL + m];
+    uB[m] = own[m];
+    uC[2 * NL + m] = own[2 * NL + m];
+  }
+  const double* __restrict__ SL = T.SK[0];
+  const double* __restrict__ SU = T.SK[1];
+  if (vL) {
+    mv_acc_ld<NL, NT>(SL + 0 * NL * NT, NT, own, yH, -1.0);
+    mv_acc_ld<NL, NT>(SL + 1 * NL * NT, NT, own, yD, -1.0);
+    mv_acc_ld<NL, NT>(SL + 2 * NL * NT, NT, own, yV, -1.0);
+    mv_acc_ld<NL, NT>(SU + 1 * NL * NT, NT, uA, yD, -1.0);
+  }
+  if (vB) mv_acc_ld<NL, NT>(SU + 0 * NL * NT, NT, uB, yH, -1.0);
+  if (vW) mv_acc_ld<NL, NT>(SU + 2 * NL * NT, NT, uC, yV, -1.0);
+}
+
+// per-corner facts on a single-rank, non-periodic mesh
+struct CornerInfo {
+  bool exists, in_x, in_y, below, left;
+  int vH, vV;  // block-Jacobi variants of the corner's H and V edge
+  long o;      // offset of the corner inside a trace plane
+};
+__device__ __forceinline__ CornerInfo corner_info(const Geo& g, int i, int j) {
+  CornerInfo c;
+  c.exists = i >= 0 && i <= g.nx && j >= 0 && j <= g.ny;
+  c.in_x = c.exists && i < g.nx;
+  c.in_y = c.exists && j < g.ny;
+  c.below = j > 0;
+  c.left = i > 0;
+  c.vH = j == 0 ? 1 : (j == g.ny ? 2 : 0);
+  c.vV = i == 0 ? 1 : (i == g.nx ? 2 : 0);
+  c.o = (long)(j + GH) * g.P + i;
+  return c;
+}
+// the corner's edge values of a global trace vector, local-edge order (H, D, V), zero where the edge does not exist
+template <int NL>
+__device__ __forceinline__ void load_corner(const double* __restrict__ v, const Geo& g, const CornerInfo& c, double* e) {
+#pragma unroll
+  for (int m = 0; m < NL; m++) {
+    e[m] = c.in_x ? v[((long)0 * NL + m) * g.G + c.o] : 0.0;
+    e[NL + m] = (c.in_x && c.in_y) ? v[((long)2 * NL + m) * g.G + c.o] : 0.0;
+    e[2 * NL + m] = c.in_y ? v[((long)1 * NL + m) * g.G + c.o] : 0.0;
+  }
+}
+template <int NL>
+__device__ __forceinline__ void store_corner(double* __restrict__ v, const Geo& g, const CornerInfo& c, const double* e) {
+#pragma unroll
+  for (int m = 0; m < NL; m++) {
+    v[((long)0 * NL + m) * g.G + c.o] = c.in_x ? e[m] : 0.0;
+    v[((long)2 * NL + m) * g.G + c.o] = (c.in_x && c.in_y) ? e[NL + m] : 0.0;
+    v[((long)1 * NL + m) * g.G + c.o] = c.in_y ? e[2 * NL + m] : 0.0;
+  }
+}
+// z = sc * Dinv r at the corner's three edges (local-edge order), zero where the edge does not exist
+// The interior variant (both cells present) is applied to every lane through WAVE-UNIFORM table pointers (scalar loads);
+// the few lanes on the mesh boundary redo their edge with the one-cell variant.  (With the variant chosen per lane every
+// table entry became a vector load: 27 per application and corner.)  r holds zeros where an edge does not exist.
+template <int NL>
+__device__ __forceinline__ void corner_dinv(const DevTables& T, const CornerInfo& c, double sc, const double* r, double* z) {
+#pragma unroll
+  for (int q = 0; q < 3 * NL; q++) z[q] = 0.0;
+  mv_acc_ld<NL, NL>(T.trDinv[0][0], NL, r, z, sc);
+  mv_acc_ld<NL, NL>(T.trDinv[2][0], NL, r + NL, z + NL, sc);
+  mv_acc_ld<NL, NL>(T.trDinv[1][0], NL, r + 2 * NL, z + 2 * NL, sc);
+  if (c.vH != 0) {
+#pragma unroll
+    for (int q = 0; q < NL; q++) z[q] = 0.0;
+    mv_acc_ld<NL, NL>(T.trDinv[0][c.vH], NL, r, z, sc);
+  }
+  if (c.vV != 0) {
+#pragma unroll
+    for (int q = 0; q < NL; q++) z[2 * NL + q] = 0.0;
+    mv_acc_ld<NL, NL>(T.trDinv[1][c.vV], NL, r + 2 * NL, z + 2 * NL, sc);
+  }
+}
+// LDS slot of local-edge entry q (0..NT-1: H modes, D modes, V modes) in plane order (H = 0, V = 1, D = 2)
+template <int NL>
+__device__ __forceinline__ int plane_of(int q) { return q < NL ? q : (q < 2 * NL ? 2 * NL + (q - NL) : NL + (q - 2 * NL)); }
+
+template <int K>
+__global__ __launch_bounds__(TraceTile<K>::NTHREADS) void k_trace_pre_tile(Geo g, DevTables T, const double* __restrict__ r, double c0, double c1,
+                                                         double c2, double* __restrict__ z_out, double* __restrict__ res_out) {
+  typedef TraceTile<K> TT;
+  constexpr int NL = TT::NL, NT = TT::NT, TW = TT::TW, TH = TT::TH, W2 = TT::W2, H2 = TT::H2, W1 = TT::W1, H1 = TT::H1, KMAX = TT::KMAX;
+  __shared__ double Ds[NT * TT::N2];  // d0 on the halo-2 region
+  __shared__ double Zs[NT * TT::N1];  // z on the halo-1 region
+  const int i0 = blockIdx.x * TW, j0 = blockIdx.y * TH;
+  double rr[KMAX][NT], dd[KMAX][NT];
+  // stage 1: d0 = c0 Dinv r on the halo-2 region (pointwise); r and d0 of this thread's corners stay in registers
+#pragma unroll
+  for (int k = 0; k < KMAX; k++) {
+    const int idx = threadIdx.x + k * TT::NTHREADS;
+    if (idx < TT::N2) {
+      const int lj = idx / W2, li = idx - lj * W2;
+      const CornerInfo c = corner_info(g, i0 - 2 + li, j0 - 2 + lj);
+      load_corner<NL>(r, g, c, rr[k]);
+      corner_dinv<NL>(T, c, c0, rr[k], dd[k]);
+#pragma unroll
+      for (int q = 0; q < NT; q++) Ds[(plane_of<NL>(q) * H2 + lj) * W2 + li] = dd[k][q];
+    }
+  }
+  __syncthreads();
+  // stage 2 on the halo-1 region: z = d0 + c1 d0 + c2 Dinv (r - T d0)
+#pragma unroll
+  for (int k = 0; k < KMAX; k++) {
+    const int idx = threadIdx.x + k * TT::NTHREADS;
+    if (idx < TT::N2) {
+      const int lj = idx / W2, li = idx - lj * W2;
+      if (li >= 1 && li < W2 - 1 && lj >= 1 && lj < H2 - 1) {
+        const CornerInfo c = corner_info(g, i0 - 2 + li, j0 - 2 + lj);
+        double z[NT];
+#pragma unroll
+        for (int q = 0; q < NT; q++) z[q] = 0.0;
+        if (c.exists) {
+          double own[NT], y[3][NL], r1[NT], zz[NT];
+          lds_trace_stencil<K, W2, H2>(Ds, li, lj, c.in_x, c.in_y, c.below, c.left, T, own, y[0], y[1], y[2]);
+#pragma unroll
+          for (int m = 0; m < NL; m++) {  // y[0] = H, y[1] = V, y[2] = D; local-edge order is H, D, V
+            r1[m] = rr[k][m] - y[0][m];
+            r1[NL + m] = rr[k][NL + m] - y[2][m];
+            r1[2 * NL + m] = rr[k][2 * NL + m] - y[1][m];
+          }
+          corner_dinv<NL>(T, c, c2, r1, zz);
+#pragma unroll
+          for (int q = 0; q < NT; q++) z[q] = dd[k][q] + fma(c1, dd[k][q], zz[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < NT; q++) Zs[(plane_of<NL>(q) * H1 + (lj - 1)) * W1 + (li - 1)] = z[q];
+        if (c.exists && li >= 2 && li < W2 - 2 && lj >= 2 && lj < H2 - 2) store_corner<NL>(z_out, g, c, z);
+      }
+    }
+  }
+  __syncthreads();
+  // stage 3 on the tile: res = r - T z
+#pragma unroll
+  for (int k = 0; k < KMAX; k++) {
+    const int idx = threadIdx.x + k * TT::NTHREADS;
+    if (idx < TT::N2) {
+      const int lj = idx / W2, li = idx - lj * W2;
+      if (li >= 2 && li < W2 - 2 && lj >= 2 && lj < H2 - 2) {
+        const CornerInfo c = corner_info(g, i0 - 2 + li, j0 - 2 + lj);
+        if (c.exists) {
+          double own[NT], y[3][NL], res[NT];
+          lds_trace_stencil<K, W1, H1>(Zs, li - 1, lj - 1, c.in_x, c.in_y, c.below, c.left, T, own, y[0], y[1], y[2]);
+#pragma unroll
+          for (int m = 0; m < NL; m++) {
+            res[m] = rr[k][m] - y[0][m];
+            res[NL + m] = rr[k][NL + m] - y[2][m];
+            res[2 * NL + m] = rr[k][2 * NL + m] - y[1][m];
+          }
+          store_corner<NL>(res_out, g, c, res);
+        }
+      }
+    }
+  }
+}
+
+template <int K>
+__global__ __launch_bounds__(TraceTile<K>::NTHREADS) void k_trace_post_tile(Geo g, DevTables T, const double* __restrict__ z_in, const double* __restrict__ r,
+                                                          const double* __restrict__ xc, double sH, double sV, double sD, double c0,
+                                                          double c1, double c2, double* __restrict__ z_out, double* __restrict__ w_out) {
+  typedef TraceTile<K> TT;
+  constexpr int NL = TT::NL, NT = TT::NT, TW = TT::TW, TH = TT::TH, W2 = TT::W2, H2 = TT::H2, W3 = TT::W3, H3 = TT::H3, KMAX = TT::KMAX;
+  __shared__ double Zs[NT * TT::N3];  // z0 on the halo-3 region; later z2 on its halo-1 part
+  __shared__ double Ds[NT * TT::N2];  // d0 on the halo-2 region
+  const int i0 = blockIdx.x * TW, j0 = blockIdx.y * TH;
+  const int st = g.nx + 1;
+  // stage 0: z0 = z + P xc on the halo-3 region (pointwise; zero outside the mesh)
+  for (int idx = threadIdx.x; idx < TT::N3; idx += TT::NTHREADS) {
+    const int lj = idx / W3, li = idx - lj * W3;
+    const int i = i0 - 3 + li, j = j0 - 3 + lj;
+    const CornerInfo c = corner_info(g, i, j);
+    double z[NT];
+    load_corner<NL>(z_in, g, c, z);
+    if (c.exists) {
+      const double v00 = xc[(long)j * st + i];
+      const double v10 = c.in_x ? xc[(long)j * st + i + 1] : 0.0, v01 = c.in_y ? xc[(long)(j + 1) * st + i] : 0.0;
+      if (c.in_x) edge_prolong(v00, v10, sH, z);
+      if (c.in_x && c.in_y) edge_prolong(v10, v01, sD, z + NL);
+      if (c.in_y) edge_prolong(v00, v01, sV, z + 2 * NL);
+    }
+#pragma unroll
+    for (int q = 0; q < NT; q++) Zs[(plane_of<NL>(q) * H3 + lj) * W3 + li] = z[q];
+  }
+  __syncthreads();
+  double r0[KMAX][NT], z1[KMAX][NT], d0[KMAX][NT];
+  // stage 1 on the halo-2 region: r0 = r - T z0, d0 = c0 Dinv r0, z1 = z0 + d0
+#pragma unroll
+  for (int k = 0; k < KMAX; k++) {
+    const int idx = threadIdx.x + k * TT::NTHREADS;
+    if (idx < TT::N2) {
+      const int lj = idx / W2, li = idx - lj * W2;
+      const CornerInfo c = corner_info(g, i0 - 2 + li, j0 - 2 + lj);
+#pragma unroll
+      for (int q = 0; q < NT; q++) r0[k][q] = z1[k][q] = d0[k][q] = 0.0;
+      if (c.exists) {
+        double own[NT], y[3][NL], rr[NT];
+        lds_trace_stencil<K, W3, H3>(Zs, li + 1, lj + 1, c.in_x, c.in_y, c.below, c.left, T, own, y[0], y[1], y[2]);
+        load_corner<NL>(r, g, c, rr);
+#pragma unroll
+        for (int m = 0; m < NL; m++) {
+          r0[k][m] = rr[m] - y[0][m];
+          r0[k][NL + m] = rr[NL + m] - y[2][m];
+          r0[k][2 * NL + m] = rr[2 * NL + m] - y[1][m];
+        }
+        corner_dinv<NL>(T, c, c0, r0[k], d0[k]);
+#pragma unroll
+        for (int q = 0; q < NT; q++) z1[k][q] = own[q] + d0[k][q];
+      }
+#pragma unroll
+      for (int q = 0; q < NT; q++) Ds[(plane_of<NL>(q) * H2 + lj) * W2 + li] = d0[k][q];
+    }
+  }
+  __syncthreads();
+  // stage 2 on the halo-1 region: r1 = r0 - T d0, d1 = c1 d0 + c2 Dinv r1, z2 = z1 + d1 (stored over z0, which is dead)
+#pragma unroll
+  for (int k = 0; k < KMAX; k++) {
+    const int idx = threadIdx.x + k * TT::NTHREADS;
+    if (idx < TT::N2) {
+      const int lj = idx / W2, li = idx - lj * W2;
+      if (li >= 1 && li < W2 - 1 && lj >= 1 && lj < H2 - 1) {
+        const CornerInfo c = corner_info(g, i0 - 2 + li, j0 - 2 + lj);
+        double z2[NT];
+#pragma unroll
+        for (int q = 0; q < NT; q++) z2[q] = 0.0;
+        if (c.exists) {
+          double own[NT], y[3][NL], r1[NT], zz[NT];
+          lds_trace_stencil<K, W2, H2>(Ds, li, lj, c.in_x, c.in_y, c.below, c.left, T, own, y[0], y[1], y[2]);
+#pragma unroll
+          for (int m = 0; m < NL; m++) {
+            r1[m] = r0[k][m] - y[0][m];
+            r1[NL + m] = r0[k][NL + m] - y[2][m];
+            r1[2 * NL + m] = r0[k][2 * NL + m] - y[1][m];
+          }
+          corner_dinv<NL>(T, c, c2, r1, zz);
+#pragma unroll
+          for (int q = 0; q < NT; q++) z2[q] = z1[k][q] + fma(c1, d0[k][q], zz[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < NT; q++) Zs[(plane_of<NL>(q) * H3 + (lj + 1)) * W3 + (li + 1)] = z2[q];
+        if (c.exists && li >= 2 && li < W2 - 2 && lj >= 2 && lj < H2 - 2) store_corner<NL>(z_out, g, c, z2);
+      }
+    }
+  }
+  if (!w_out) return;  // uniform
+  __syncthreads();
+  // stage 3 on the tile: w = T z2
+#pragma unroll
+  for (int k = 0; k < KMAX; k++) {
+    const int idx = threadIdx.x + k * TT::NTHREADS;
+    if (idx < TT::N2) {
+      const int lj = idx / W2, li = idx - lj * W2;
+      if (li >= 2 && li < W2 - 2 && lj >= 2 && lj < H2 - 2) {
+        const CornerInfo c = corner_info(g, i0 - 2 + li, j0 - 2 + lj);
+        if (c.exists) {
+          double own[NT], y[3][NL], w[NT];
+          lds_trace_stencil<K, W3, H3>(Zs, li + 1, lj + 1, c.in_x, c.in_y, c.below, c.left, T, own, y[0], y[1], y[2]);
+#pragma unroll
+          for (int m = 0; m < NL; m++) { w[m] = y[0][m]; w[NL + m] = y[2][m]; w[2 * NL + m] = y[1][m]; }
+          store_corner<NL>(w_out, g, c, w);
+        }
+      }
+    }
+  }
+}
+
+}  // namespace hdg
