@@ -2214,8 +2214,12 @@ struct Engine {
     // k = 4: the post kernel needs 274 VGPRs (15 trace values per corner and stage): 5.88 instead of 5.65 ms per solve at 512^2
     return !off && fuse && nsm == 2 && cfg.trace_precond == 1 && comm->size == 1 && !periodic && !general && halo_on && K <= 3;
   }
-  // returns true when w_out has received T z (the operator application the single-reduction CG needs next)
-  bool trace_precond(const double* r, double* z, double* w_out = nullptr) {
+  // returns true when w_out has received T z (the operator application the single-reduction CG needs next); with
+  // dots_out set as well, d_res then holds (z,n), (z,r), (z,z), (z,w), (n,r) (the multi-dot of that CG: *dots_out = true)
+  double* tile_part = nullptr;
+  long tile_part_cap = 0;
+  bool trace_precond(const double* r, double* z, double* w_out = nullptr, bool* dots_out = nullptr) {
+    if (dots_out) *dots_out = false;
     if (cfg.trace_precond == 0) {
       zero(z, NLv);
       trace_cheb(r, ch_d, z, 0.0, 1.0);
@@ -2236,8 +2240,24 @@ struct Engine {
         k_trace_to_p1<<<corner_grid_all(), bs(), 0, stream>>>(g_all, NL, wL2, mg_b[0], dt.elen[0], dt.elen[2], dt.elen[1], 0);
         run_vcycle();
         tally(LC_TRACE_SMOOTH, (w_out ? 4 : 3) * bL() + nvtx);
-        k_trace_post_tile<KK><<<grid, TT::NTHREADS, 0, stream>>>(g, pdt(), ch_d, r, mg_x[0], std::sqrt(dt.elen[0]), std::sqrt(dt.elen[2]),
-                                                                 std::sqrt(dt.elen[1]), c0, c1, c2, z, w_out);
+        const long nblk = (long)grid.x * grid.y;
+        double* part = nullptr;
+        static const bool no_fused_dots = getenv("HDG_TRACE_NO_FUSED_DOTS") != nullptr;
+        if (w_out && dots_out && !no_fused_dots) {
+          if (tile_part_cap < nblk * 5) { tile_part = dalloc(nblk * 5); tile_part_cap = nblk * 5; }
+          part = tile_part;
+        }
+        if (part)
+          k_trace_post_tile<KK, true><<<grid, TT::NTHREADS, 0, stream>>>(g, pdt(), ch_d, r, mg_x[0], std::sqrt(dt.elen[0]), std::sqrt(dt.elen[2]),
+                                                                         std::sqrt(dt.elen[1]), c0, c1, c2, z, w_out, part);
+        else
+          k_trace_post_tile<KK, false><<<grid, TT::NTHREADS, 0, stream>>>(g, pdt(), ch_d, r, mg_x[0], std::sqrt(dt.elen[0]), std::sqrt(dt.elen[2]),
+                                                                          std::sqrt(dt.elen[1]), c0, c1, c2, z, w_out, nullptr);
+        if (part) {
+          tally(LC_OTHER, 0.0);
+          k_reduce_parts<<<5, 256, 0, stream>>>((int)nblk, 5, part, d_res);
+          *dots_out = true;
+        }
       };
       switch (K) {
         case 1: launch(std::integral_constant<int, 1>{}); break;
@@ -2439,8 +2459,9 @@ struct Engine {
     double norm0 = -1.0;
     int its = 0;
     while (true) {
-      if (!trace_precond(cg_r, cg_z, cg_Ap)) trace_apply(cg_z, nullptr, 0.0, 1.0, cg_Ap);  // w = T z
-      multidot(NLv, cg_z, {tr_one, cg_r, cg_z, cg_Ap}, nullptr, KL, true);  // (z,n), (z,r), (z,z), (z,w), (n,r) -> d_res
+      bool have_dots = false;
+      if (!trace_precond(cg_r, cg_z, cg_Ap, &have_dots)) trace_apply(cg_z, nullptr, 0.0, 1.0, cg_Ap);  // w = T z
+      if (!have_dots) multidot(NLv, cg_z, {tr_one, cg_r, cg_z, cg_Ap}, nullptr, KL, true);  // (z,n), (z,r), (z,z), (z,w), (n,r) -> d_res
       tally(LC_OTHER, 0.0);
       tally(LC_VEC, bL() * 11);  // k_cg_sr_update: reads z, n, w, p, s, x, r; writes p, s, x, r
       k_cg_sr_scalars<<<1, 1, 0, stream>>>(d_res, d_cgs, tr_one_nn, its == 0 ? 1 : 0);

@@ -33,6 +33,7 @@ struct TraceTile {
   // to 4 waves per SIMD 90 / 188 (spills).  The five row-stencil launches they replace: 60 + 37 and 97 + 78 + 37.
   static constexpr int TW = 16, TH = 8, NTHREADS = 256;
   static constexpr int W2 = TW + 4, H2 = TH + 4, N2 = W2 * H2;  // halo-2 region: the index map of every stage
+  static constexpr int WPE_POST = K == 1 ? 4 : (K == 2 ? 3 : (K == 3 ? 2 : 1));  // waves per SIMD the post kernel is held to (with the inner products too)
   static constexpr int W3 = TW + 6, H3 = TH + 6, N3 = W3 * H3;  // halo-3 region (post kernel, stage 0)
   static constexpr int W1 = TW + 2, H1 = TH + 2, N1 = W1 * H1;  // halo-1 region
   static constexpr int KMAX = (N2 + NTHREADS - 1) / NTHREADS;   // corners per thread
@@ -217,10 +218,11 @@ __global__ __launch_bounds__(TraceTile<K>::NTHREADS) void k_trace_pre_tile(Geo g
   }
 }
 
-template <int K>
-__global__ __launch_bounds__(TraceTile<K>::NTHREADS) void k_trace_post_tile(Geo g, DevTables T, const double* __restrict__ z_in, const double* __restrict__ r,
+template <int K, bool DOTS>
+__global__ __launch_bounds__(TraceTile<K>::NTHREADS) __attribute__((amdgpu_waves_per_eu(TraceTile<K>::WPE_POST))) void k_trace_post_tile(Geo g, DevTables T, const double* __restrict__ z_in, const double* __restrict__ r,
                                                           const double* __restrict__ xc, double sH, double sV, double sD, double c0,
-                                                          double c1, double c2, double* __restrict__ z_out, double* __restrict__ w_out) {
+                                                          double c1, double c2, double* __restrict__ z_out, double* __restrict__ w_out,
+                                                          double* __restrict__ part) {
   typedef TraceTile<K> TT;
   constexpr int NL = TT::NL, NT = TT::NT, TW = TT::TW, TH = TT::TH, W2 = TT::W2, H2 = TT::H2, W3 = TT::W3, H3 = TT::H3, KMAX = TT::KMAX;
   __shared__ double Zs[NT * TT::N3];  // z0 on the halo-3 region; later z2 on its halo-1 part
@@ -246,6 +248,7 @@ __global__ __launch_bounds__(TraceTile<K>::NTHREADS) void k_trace_post_tile(Geo 
   }
   __syncthreads();
   double r0[KMAX][NT], z1[KMAX][NT], d0[KMAX][NT];
+  double dots[5] = {0.0, 0.0, 0.0, 0.0, 0.0};  // (z,n), (z,r), (z,z), (z,w), (n,r) of this thread's tile corners
   // stage 1 on the halo-2 region: r0 = r - T z0, d0 = c0 Dinv r0, z1 = z0 + d0
 #pragma unroll
   for (int k = 0; k < KMAX; k++) {
@@ -320,8 +323,40 @@ __global__ __launch_bounds__(TraceTile<K>::NTHREADS) void k_trace_post_tile(Geo 
 #pragma unroll
           for (int m = 0; m < NL; m++) { w[m] = y[0][m]; w[NL + m] = y[2][m]; w[2 * NL + m] = y[1][m]; }
           store_corner<NL>(w_out, g, c, w);
+          if (DOTS) {
+            // the five inner products of the single-reduction CG from what is in registers (+ r of this corner): the
+            // separate multi-dot pass over z, n, r, w is not needed.  The null vector n (the constant) has the entry
+            // sqrt(edge length) in mode 0 of every edge that exists and zeros elsewhere -- what edge_prolong gives for
+            // vertex values 1; entries of edges that do not exist are zero in z and r.
+            double rr[NT];
+            load_corner<NL>(r, g, c, rr);
+            dots[0] += sH * own[0] + sD * own[NL] + sV * own[2 * NL];  // own = z2 of this corner (from LDS)
+            dots[4] += sH * rr[0] + sD * rr[NL] + sV * rr[2 * NL];
+#pragma unroll
+            for (int q = 0; q < NT; q++) {
+              const double zq = own[q];
+              dots[1] = fma(zq, rr[q], dots[1]);
+              dots[2] = fma(zq, zq, dots[2]);
+              dots[3] = fma(zq, w[q], dots[3]);
+            }
+          }
         }
       }
+    }
+  }
+  if (DOTS) {  // deterministic two-stage reduction (per workgroup here, k_reduce_parts over the workgroups)
+    __shared__ double sm[TT::NTHREADS / 64][5];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < 5; q++) {
+      const double sv = wave_sum(dots[q]);
+      if (lane == 0) sm[wv][q] = sv;
+    }
+    __syncthreads();
+    if (threadIdx.x < 5) {
+      double sv = 0.0;
+      for (int w2 = 0; w2 < TT::NTHREADS / 64; w2++) sv += sm[w2][threadIdx.x];
+      part[(long)(blockIdx.y * gridDim.x + blockIdx.x) * 5 + threadIdx.x] = sv;
     }
   }
 }
