@@ -97,6 +97,14 @@ struct Engine {
   std::vector<double*> gm_V;  // GMRES basis (restart+1)
   const double** d_ptrs = nullptr;
   const double** d_gmV = nullptr;  // device array of the GMRES basis pointers
+  // single-precision COPY of the GMRES basis (experiment, HDG_KRYLOV_FP32=1): the Gram-Schmidt passes and the solution update
+  // read these (half the bytes); gm_V[j] holds the same rounded values as doubles for the operator kernels.  MEASURED AND
+  // REJECTED as the default: the smooth benchmark fields make the Krylov spaces nearly invariant
+  // (h_{j+1,j} / |w| ~ 3e-4 in the first steps of a cycle), the 6e-8 rounding of v_j then enters v_{j+1} at 2e-4 relative
+  // and every solve needs about one iteration more (C3: 22.4 instead of 21.4; k = 4 at 512^2: 34.4 instead of 29.8)
+  std::vector<float*> gm_Vf;
+  const float** d_gmVf = nullptr;
+  bool basis_f32 = false;
   double* d_part = nullptr;
   double* d_res = nullptr;
   double* h_res = nullptr;  // pinned host mirror of d_res
@@ -527,6 +535,25 @@ struct Engine {
       pv.push_back(nullptr);
       pv.push_back(nullptr);
       d_gmV = upload_ptrs(pv);
+    }
+    basis_f32 = std::getenv("HDG_KRYLOV_FP32") != nullptr;
+    if (basis_f32) {
+      std::vector<const float*> pf;
+      for (int i = 0; i <= m; i++) {
+        void* q = nullptr;
+        HIPCHECK(hipMalloc(&q, sizeof(float) * (size_t)std::max<long>(NQ, 1)));
+        HIPCHECK(hipMemsetAsync(q, 0, sizeof(float) * (size_t)std::max<long>(NQ, 1), stream));
+        allocs.push_back(q);
+        gm_Vf.push_back((float*)q);
+        pf.push_back((const float*)q);
+      }
+      pf.push_back(nullptr);
+      pf.push_back(nullptr);
+      void* q = nullptr;
+      HIPCHECK(hipMalloc(&q, sizeof(float*) * pf.size()));
+      allocs.push_back(q);
+      HIPCHECK(hipMemcpy(q, pf.data(), sizeof(float*) * pf.size(), hipMemcpyHostToDevice));
+      d_gmVf = (const float**)q;
     }
     void* p = nullptr;
     HIPCHECK(hipMalloc(&p, sizeof(double*) * (std::max(m, MAXV) + 2)));
@@ -1401,13 +1428,27 @@ struct Engine {
   }
   // out = scale * (w - sum_{l < nv} h_l V_l)   (V_l: the GMRES basis gm_V)
   void gs_update(const double* w, const Coefs& h, int nv, double scale, double* out) {
-    tally(LC_VEC, bQ() * (nv + 2));
-    if (big(NQ)) k_gs_update<MAXV, true><<<vec_blocks(NQ), 256, 0, stream>>>(NQ, w, d_gmV, h, nv, scale, out);
-    else k_gs_update<MAXV, false><<<vec_blocks(NQ), 256, 0, stream>>>(NQ, w, d_gmV, h, nv, scale, out);
+    if (basis_f32) {
+      int slot = -1;
+      for (size_t q = 0; q < gm_V.size() && slot < 0; q++) if (gm_V[q] == out) slot = (int)q;
+      if (slot < 0) throw std::string("gs_update: the result is not a basis vector");
+      tally(LC_VEC, bQ() * (0.5 * nv + 2.5));
+      if (big(NQ)) k_gs_update<MAXV, true, float><<<vec_blocks(NQ), 256, 0, stream>>>(NQ, w, d_gmVf, h, nv, scale, out, gm_Vf[slot]);
+      else k_gs_update<MAXV, false, float><<<vec_blocks(NQ), 256, 0, stream>>>(NQ, w, d_gmVf, h, nv, scale, out, gm_Vf[slot]);
+    } else {
+      tally(LC_VEC, bQ() * (nv + 2));
+      if (big(NQ)) k_gs_update<MAXV, true><<<vec_blocks(NQ), 256, 0, stream>>>(NQ, w, d_gmV, h, nv, scale, out);
+      else k_gs_update<MAXV, false><<<vec_blocks(NQ), 256, 0, stream>>>(NQ, w, d_gmV, h, nv, scale, out);
+    }
+    // ghost rows: the single-precision copies are never exchanged, so they keep the depth they were created with (an
+    // exchange may have deepened the double-precision twin since): tracked under their own addresses
     int d = fl.get(w);
-    for (int l = 0; l < nv; l++) d = std::min(d, fl.get(gm_V[l]));
+    for (int l = 0; l < nv; l++) d = std::min(d, fl.get(basis_key(l)));
     fl.set(out, d);
+    if (basis_f32)
+      for (size_t q = 0; q < gm_V.size(); q++) if (gm_V[q] == out) fl.set(basis_key((int)q), d);
   }
+  const double* basis_key(int l) const { return basis_f32 ? reinterpret_cast<const double*>(gm_Vf[l]) : gm_V[l]; }
   void lincomb(long n, const std::vector<std::pair<const double*, double>>& terms, double* out) {
     // merge duplicate pointers, drop zeros, chunks of 8
     std::vector<std::pair<const double*, double>> t;
@@ -1447,6 +1488,10 @@ struct Engine {
   // dots of w against nv vectors over the OWNED entries, summed over ranks (host result); one sync
   // cross: res[nv] additionally receives (V[0], V[1]) from the same pass (nv >= 2, single chunk)
   // res == nullptr: the results stay in d_res on the device (single chunk), no host copy, no synchronisation
+  static bool direct_host() {
+    static const bool on = std::getenv("HDG_NO_DIRECT_HOST") == nullptr;
+    return on;
+  }
   void multidot(long n, const double* w, const std::vector<const double*>& V, double* res, int kind, bool cross = false) {
     int nv = (int)V.size();
     if (!res && nv > MAXV) throw std::string("multidot: device-resident result needs a single chunk");
@@ -1474,11 +1519,13 @@ struct Engine {
       else if (nout <= 6) launch(std::integral_constant<int, 6>{});
       else if (nout <= 12) launch(std::integral_constant<int, 12>{});
       else launch(std::integral_constant<int, MAXV>{});
-      k_reduce_parts<<<nout, 256, 0, stream>>>(nb, nout, d_part, d_res);
+      // one rank: the reduction kernel writes the pinned host copy itself (no copy kernel on the stream)
+      const bool direct = res && comm->size == 1 && direct_host();
+      k_reduce_parts<<<nout, 256, 0, stream>>>(nb, nout, d_part, d_res, direct ? h_res : nullptr);
       comm->allreduce_sum(d_res, nout, stream);
       n_reduce++;
       if (!res) continue;
-      HIPCHECK(hipMemcpyAsync(h_res, d_res, sizeof(double) * nout, hipMemcpyDeviceToHost, stream));  // pinned
+      if (!direct) HIPCHECK(hipMemcpyAsync(h_res, d_res, sizeof(double) * nout, hipMemcpyDeviceToHost, stream));  // pinned
       HIPCHECK(hipStreamSynchronize(stream));
       for (int q = 0; q < nout; q++) res[off + q] = h_res[q];
     }
@@ -1487,6 +1534,40 @@ struct Engine {
     double r;
     multidot(n, a, {b}, &r, kind);
     return r;
+  }
+  // Gram-Schmidt pass of the tentative-velocity GMRES: res[l] = (w, V_l), l < nb, and res[nb] = (w, w) in one pass over w
+  // and the basis (its single-precision copy when there is one)
+  void multidot_basis(const double* w, int nb_, double* res) {
+    if (!basis_f32) {
+      std::vector<const double*> ptrs(gm_V.begin(), gm_V.begin() + nb_);
+      ptrs.push_back(w);
+      multidot(NQ, w, ptrs, res, KQ);
+      return;
+    }
+    const int cnt = nb_ + 1;
+    if (cnt > MAXV) throw std::string("multidot_basis: too many vectors");
+    const int nb = std::min(dot_blocks, vec_blocks(NQ));
+    const RowMask mk = mask_for(KQ);
+    tally(LC_DOT, bvec(NQ) * (0.5 * nb_ + 1));
+    tally(LC_OTHER, 0.0);  // k_reduce_parts
+    auto launch = [&](auto tag) {
+      constexpr int MV = decltype(tag)::value;
+      VecList<MV, float> vl;
+      for (int q = 0; q < MV; q++) vl.p[q] = q < nb_ ? gm_Vf[q] : nullptr;
+      if (big(NQ)) k_multidot<MV, true, float><<<nb, HDG_DOT_BLOCK, 0, stream>>>(NQ, w, vl, cnt, d_part, mk, 0, nb_);
+      else k_multidot<MV, false, float><<<nb, HDG_DOT_BLOCK, 0, stream>>>(NQ, w, vl, cnt, d_part, mk, 0, nb_);
+    };
+    if (cnt <= 4) launch(std::integral_constant<int, 4>{});
+    else if (cnt <= 6) launch(std::integral_constant<int, 6>{});
+    else if (cnt <= 12) launch(std::integral_constant<int, 12>{});
+    else launch(std::integral_constant<int, MAXV>{});
+    const bool direct = comm->size == 1 && direct_host();
+    k_reduce_parts<<<cnt, 256, 0, stream>>>(nb, cnt, d_part, d_res, direct ? h_res : nullptr);
+    comm->allreduce_sum(d_res, cnt, stream);
+    n_reduce++;
+    if (!direct) HIPCHECK(hipMemcpyAsync(h_res, d_res, sizeof(double) * cnt, hipMemcpyDeviceToHost, stream));  // pinned
+    HIPCHECK(hipStreamSynchronize(stream));
+    for (int q = 0; q < cnt; q++) res[q] = h_res[q];
   }
   // ------------------------------------------------------------------ pressure mean shift
   void shift(double* p, double* l) {
@@ -1686,12 +1767,7 @@ struct Engine {
         tent_precond(didx, t, w);
         // one pass: h_l = (w, V_l), l <= j, and (w, w); then ||w - V h||^2 = (w,w) - sum h_l^2
         std::vector<double> h(j + 2);
-        {
-          // pointer list = V_0..V_j followed by w: gather through a small staging array
-          std::vector<const double*> ptrs(gm_V.begin(), gm_V.begin() + j + 1);
-          ptrs.push_back(w);
-          multidot(NQ, w, ptrs, h.data(), KQ);
-        }
+        multidot_basis(w, j + 1, h.data());
         double ww = h[j + 1], s2 = 0.0;
         for (int l = 0; l <= j; l++) s2 += h[l] * h[l];
         double hn2 = ww - s2;
@@ -1705,7 +1781,7 @@ struct Engine {
           // severe cancellation: orthogonalise explicitly and measure the norm (safe path)
           gs_update(w, hc, j + 1, 1.0, gm_V[j + 1]);
           hn = std::sqrt(dot(NQ, gm_V[j + 1], gm_V[j + 1], KQ));
-          if (hn > 0) axpby(NQ, 0.0, w, 1.0 / hn, gm_V[j + 1]);
+          if (hn > 0) gs_update(w, hc, j + 1, 1.0 / hn, gm_V[j + 1]);  // once more with the norm (writes every copy of the vector)
         }
         for (int l = 0; l <= j; l++) H[(size_t)l * m + j] = h[l];
         H[(size_t)(j + 1) * m + j] = hn;
@@ -1730,6 +1806,7 @@ struct Engine {
         its++;
         double res = std::fabs(gv[j + 1]);
         if (beta_last) *beta_last = res;
+        if (debug_on()) fprintf(stderr, "[gmres]   it %d (cycle start %.3e)  estimate %.3e  hn %.3e\n", its, beta / beta0, res / beta0, hn);
         if (res <= rtol * beta0 || hn == 0.0) { j++; done = true; break; }
         if (its >= maxit) { j++; done = false; break; }
       }
@@ -1741,12 +1818,15 @@ struct Engine {
         y[l] = acc / H[(size_t)l * m + l];
       }
       for (int l = 0; l < j; l++) yc.c[l] = y[l];
-      tally(LC_VEC, bQ() * (j + 2));
-      if (big(NQ)) k_basis_axpy<MAXV, true><<<nvb, 256, 0, stream>>>(NQ, x, d_gmV, yc, j);
+      tally(LC_VEC, bQ() * ((basis_f32 ? 0.5 : 1.0) * j + 2));
+      if (basis_f32) {
+        if (big(NQ)) k_basis_axpy<MAXV, true, float><<<nvb, 256, 0, stream>>>(NQ, x, d_gmVf, yc, j);
+        else k_basis_axpy<MAXV, false, float><<<nvb, 256, 0, stream>>>(NQ, x, d_gmVf, yc, j);
+      } else if (big(NQ)) k_basis_axpy<MAXV, true><<<nvb, 256, 0, stream>>>(NQ, x, d_gmV, yc, j);
       else k_basis_axpy<MAXV, false><<<nvb, 256, 0, stream>>>(NQ, x, d_gmV, yc, j);
       {
         int d = fl.get(x);
-        for (int l = 0; l < j; l++) d = std::min(d, fl.get(gm_V[l]));
+        for (int l = 0; l < j; l++) d = std::min(d, fl.get(basis_key(l)));
         fl.set(x, d);
       }
       if (ritz) {
@@ -2464,8 +2544,8 @@ struct Engine {
       if (!have_dots) multidot(NLv, cg_z, {tr_one, cg_r, cg_z, cg_Ap}, nullptr, KL, true);  // (z,n), (z,r), (z,z), (z,w), (n,r) -> d_res
       tally(LC_OTHER, 0.0);
       tally(LC_VEC, bL() * 11);  // k_cg_sr_update: reads z, n, w, p, s, x, r; writes p, s, x, r
-      k_cg_sr_scalars<<<1, 1, 0, stream>>>(d_res, d_cgs, tr_one_nn, its == 0 ? 1 : 0);
-      HIPCHECK(hipMemcpyAsync(h_cgs, d_cgs, sizeof(double) * 8, hipMemcpyDeviceToHost, stream));
+      k_cg_sr_scalars<<<1, 1, 0, stream>>>(d_res, d_cgs, tr_one_nn, its == 0 ? 1 : 0, direct_host() ? h_cgs : nullptr);  // + snapshot in pinned memory
+      if (!direct_host()) HIPCHECK(hipMemcpyAsync(h_cgs, d_cgs, sizeof(double) * 8, hipMemcpyDeviceToHost, stream));
       HIPCHECK(hipEventRecord(cg_ev, stream));
       k_cg_sr_update<<<nvb, 256, 0, stream>>>(NLv, d_cgs, cg_z, tr_one, cg_Ap, cg_p, cg_s, x, cg_r);
       fl.set(cg_s, its == 0 ? fl.get(cg_Ap) : std::min(fl.get(cg_s), fl.get(cg_Ap)));

@@ -1825,6 +1825,14 @@ __device__ __forceinline__ hdg_d2 ldv(const double* p, long i) { return NT ? __b
 template <bool NT>
 __device__ __forceinline__ void stv(double* p, long i, hdg_d2 v) { if (NT) __builtin_nontemporal_store(v, as2(p) + i); else as2(p)[i] = v; }
 __device__ __forceinline__ hdg_d2 fma2(double a, hdg_d2 x, hdg_d2 y) { return hdg_d2{fma(a, x.x, y.x), fma(a, x.y, y.y)}; }
+// single-precision STORAGE of a Krylov basis (arithmetic stays FP64): a pair of floats widened on load
+typedef float hdg_f2 __attribute__((ext_vector_type(2)));
+template <bool NT>
+__device__ __forceinline__ hdg_d2 ldv(const float* p, long i) {
+  const hdg_f2* q = reinterpret_cast<const hdg_f2*>(p) + i;
+  const hdg_f2 v = NT ? __builtin_nontemporal_load(q) : *q;
+  return hdg_d2{(double)v.x, (double)v.y};
+}
 
 struct LinComb {
   const double* v[8];
@@ -1915,7 +1923,8 @@ __global__ void k_cg_p_dev(long N, const double* __restrict__ z, const double* _
 // recurrence s = w + beta s.  A n = 0 and A symmetric: (w, z') = (w, z) up to rounding.
 //   res = (z,n), (z,r), (z,z), (z,w), (n,r);  nn = (n,n);  sc[] as above
 // Zero residual (gamma = 0): alpha = beta = 0, the update is the identity and the host returns after the snapshot.
-__global__ void k_cg_sr_scalars(const double* __restrict__ res, double* __restrict__ sc, double nn, int first) {
+__global__ void k_cg_sr_scalars(const double* __restrict__ res, double* __restrict__ sc, double nn, int first,
+                                double* __restrict__ hsc = nullptr) {
   const double c = res[0] / nn;
   const double rzn = res[1] - c * res[4];
   const double zz = res[2] - c * res[0];
@@ -1932,6 +1941,10 @@ __global__ void k_cg_sr_scalars(const double* __restrict__ res, double* __restri
   sc[2] = (rzn == 0.0) ? 0.0 : beta;
   sc[1] = alpha;
   sc[0] = rzn;
+  if (hsc) {  // snapshot for the host's lagged convergence check (pinned memory; read after the event behind this kernel)
+#pragma unroll
+    for (int q = 0; q < 8; q++) hsc[q] = sc[q];
+  }
 }
 //   p = (z - c n) + beta p ;  s = w + beta s ;  x += alpha p ;  r -= alpha s       (one pass; whole arrays, ghost rows too)
 __global__ void k_cg_sr_update(long N, const double* __restrict__ sc, const double* __restrict__ z, const double* __restrict__ nvec,
@@ -1996,13 +2009,14 @@ __device__ __forceinline__ double row_factor(const RowMask& mk, long N, long idx
   return (row < mk.lo || row > mk.hi) ? 0.0 : 1.0;
 }
 // vector list passed by value (kernel arguments): no host->device pointer upload per call
-template <int MAXV>
+template <int MAXV, typename TV = double>
 struct VecList {
-  const double* p[MAXV];
+  const TV* p[MAXV];
 };
-template <int MAXV, bool NT>
+// TV = float: the vectors of the list are a single-precision Krylov basis (V[self], if any, is still w itself)
+template <int MAXV, bool NT, typename TV = double>
 __global__ __launch_bounds__(HDG_DOT_BLOCK) void k_multidot(long N, const double* __restrict__ w,
-                                                             const VecList<MAXV> V, int nv,
+                                                             const VecList<MAXV, TV> V, int nv,
                                                              double* __restrict__ part, RowMask mk, int cross, int self = -1) {
   __shared__ double sm[HDG_DOT_BLOCK / 64][MAXV];
   double acc[MAXV];
@@ -2054,8 +2068,8 @@ __global__ __launch_bounds__(HDG_DOT_BLOCK) void k_multidot(long N, const double
   }
   if (tail_) {
     const double mf = mk.w_ > 0 ? row_factor(mk, N, it_) : 1.0;
-    for (int k = 0; k < nv; k++) acc[k] = fma(w[it_] * mf, V.p[k][it_], acc[k]);
-    if (cross) accx = fma(mf * V.p[0][it_], V.p[1][it_], accx);
+    for (int k = 0; k < nv; k++) acc[k] = fma(w[it_] * mf, k == self ? w[it_] : (double)V.p[k][it_], acc[k]);
+    if (cross) accx = fma(mf * (double)V.p[0][it_], (double)V.p[1][it_], accx);
   }
   const int nvo = nv + (cross ? 1 : 0);
   const int lane = threadIdx.x & 63, wv_ = threadIdx.x >> 6;
@@ -2077,7 +2091,10 @@ __global__ __launch_bounds__(HDG_DOT_BLOCK) void k_multidot(long N, const double
     part[(long)blockIdx.x * nvo + threadIdx.x] = s;
   }
 }
-__global__ void k_reduce_parts(int nblocks, int nv, const double* __restrict__ part, double* __restrict__ res) {
+// hres != nullptr: the result goes to pinned host memory as well (the host reads it after a stream / event synchronisation:
+// no copy kernel, which costs 8 us on the stream)
+__global__ void k_reduce_parts(int nblocks, int nv, const double* __restrict__ part, double* __restrict__ res,
+                               double* __restrict__ hres = nullptr) {
   const int k = blockIdx.x;
   double acc = 0.0;
   for (int b = threadIdx.x; b < nblocks; b += blockDim.x) acc += part[(long)b * nv + k];
@@ -2089,6 +2106,7 @@ __global__ void k_reduce_parts(int nblocks, int nv, const double* __restrict__ p
     double tot = 0.0;
     for (int w = 0; w < (int)(blockDim.x >> 6); w++) tot += sm[w];
     res[k] = tot;
+    if (hres) hres[k] = tot;
   }
 }
 // Chebyshev step on velocity vectors, three-term form:  pn = x + c1 (x - pn) + c2 z   (pn: x_{n-1} -> x_{n+1})
@@ -2113,26 +2131,42 @@ struct Coefs {
   double c[32];
 };
 // out = scale * (w - sum_k h[k] V[k])     (classical Gram-Schmidt update fused with the normalisation)
-template <int MAXV, bool NT>
-__global__ void k_gs_update(long N, const double* __restrict__ w, const double* const* __restrict__ V, Coefs h, int nv,
-                            double scale, double* __restrict__ out) {
+// TV = float (single-precision basis storage): the new vector is ROUNDED to single precision, stored in outf, and out
+// receives the same rounded values as doubles (the operator kernels read doubles): the Arnoldi relation then holds for
+// one and the same set of vectors, only their orthonormality is accurate to single precision
+template <int MAXV, bool NT, typename TV = double>
+__global__ void k_gs_update(long N, const double* __restrict__ w, const TV* const* __restrict__ V, Coefs h, int nv,
+                            double scale, double* __restrict__ out, float* __restrict__ outf = nullptr) {
+  constexpr bool F32 = sizeof(TV) == 4;
   HDG_VEC_PROLOGUE
   for (long i = tid_; i < NP2_; i += stride_) {
     hdg_d2 acc = ldv<NT>(w, i);
 #pragma unroll
     for (int k = 0; k < MAXV; k++)
       if (k < nv) acc = fma2(-h.c[k], ldv<NT>(V[k], i), acc);
-    stv<NT>(out, i, hdg_d2{scale * acc.x, scale * acc.y});
+    if (F32) {
+      const hdg_f2 f{(float)(scale * acc.x), (float)(scale * acc.y)};
+      reinterpret_cast<hdg_f2*>(outf)[i] = f;
+      stv<NT>(out, i, hdg_d2{(double)f.x, (double)f.y});
+    } else {
+      stv<NT>(out, i, hdg_d2{scale * acc.x, scale * acc.y});
+    }
   }
   if (tail_) {
     double acc = w[it_];
-    for (int k = 0; k < nv; k++) acc = fma(-h.c[k], V[k][it_], acc);
-    out[it_] = scale * acc;
+    for (int k = 0; k < nv; k++) acc = fma(-h.c[k], (double)V[k][it_], acc);
+    if (F32) {
+      const float f = (float)(scale * acc);
+      outf[it_] = f;
+      out[it_] = (double)f;
+    } else {
+      out[it_] = scale * acc;
+    }
   }
 }
 // x += sum_k y[k] V[k]
-template <int MAXV, bool NT>
-__global__ void k_basis_axpy(long N, double* __restrict__ x, const double* const* __restrict__ V, Coefs y, int nv) {
+template <int MAXV, bool NT, typename TV = double>
+__global__ void k_basis_axpy(long N, double* __restrict__ x, const TV* const* __restrict__ V, Coefs y, int nv) {
   HDG_VEC_PROLOGUE
   for (long i = tid_; i < NP2_; i += stride_) {
     hdg_d2 acc = ldv<NT>(x, i);
@@ -2143,7 +2177,7 @@ __global__ void k_basis_axpy(long N, double* __restrict__ x, const double* const
   }
   if (tail_) {
     double acc = x[it_];
-    for (int k = 0; k < nv; k++) acc = fma(y.c[k], V[k][it_], acc);
+    for (int k = 0; k < nv; k++) acc = fma(y.c[k], (double)V[k][it_], acc);
     x[it_] = acc;
   }
 }

@@ -2,7 +2,7 @@ cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-forma
 cd $GRAFT_REPO_ROOT; f=$(find gpurun_out/prof_tile -name "*kernel_stats.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv, sys
-for r in list(csv.DictReader(open(sys.argv[1])))[:14]:
+for r in list(csv.DictReader(open(sys.argv[1])))[:int(__import__("os").environ.get("NROWS", "14"))]:
     print(f"{r['Name'][:70]:70s} {r['Calls']:>5s} {float(r['AverageNs'])/1e3:8.1f} us {r['Percentage']}")
 PY
 rm -rf gpurun_out/prof_tile
