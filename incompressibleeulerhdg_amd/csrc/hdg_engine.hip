@@ -35,6 +35,7 @@
 #include "hdg_tables.hpp"
 #include "hdg_general.hpp"
 #include "hdg_general_kernels.hpp"
+#include "hdg_amg.hpp"
 
 namespace hdg {
 
@@ -282,13 +283,98 @@ struct Engine {
     d.rowptr = upload_ints(m.rowptr);
     d.col = upload_ints(m.col);
     d.val = upload(m.val.empty() ? dvec(1, 0.0) : m.val);
+    const double avg = m.nrows > 0 ? (double)m.val.size() / m.nrows : 0.0;
+    d.tpr = avg <= 3.0 ? 1 : (avg <= 6.0 ? 2 : (avg <= 12.0 ? 4 : (avg <= 24.0 ? 8 : (avg <= 48.0 ? 16 : (avg <= 96.0 ? 32 : 64)))));
     return d;
   }
   // y = beta y + alpha A x
   void csr(const DevCsr& A, const double* x, double alpha, double beta, double* y) {
     tally(LC_OTHER, 12.0 * A.nnz + 8.0 * (A.ncols + A.nrows * (beta != 0.0 ? 2 : 1)));
-    k_csr_apply<<<(A.nrows + 127) / 128, 128, 0, stream>>>(A, x, alpha, beta, y);
+    const long nthr = (long)A.nrows * A.tpr;
+    const int nblk = (int)((nthr + 255) / 256);
+    switch (A.tpr) {
+      case 1: k_csr_apply<1><<<nblk, 256, 0, stream>>>(A, x, alpha, beta, y); break;
+      case 2: k_csr_apply<2><<<nblk, 256, 0, stream>>>(A, x, alpha, beta, y); break;
+      case 4: k_csr_apply<4><<<nblk, 256, 0, stream>>>(A, x, alpha, beta, y); break;
+      case 8: k_csr_apply<8><<<nblk, 256, 0, stream>>>(A, x, alpha, beta, y); break;
+      case 16: k_csr_apply<16><<<nblk, 256, 0, stream>>>(A, x, alpha, beta, y); break;
+      case 32: k_csr_apply<32><<<nblk, 256, 0, stream>>>(A, x, alpha, beta, y); break;
+      default: k_csr_apply<64><<<nblk, 256, 0, stream>>>(A, x, alpha, beta, y); break;
+    }
     fl.set(y, 0);
+  }
+  // P1 coarse space of the trace preconditioner on a general mesh and its algebraic hierarchy (hdg_amg.hpp)
+  struct AmgDev {
+    DevCsr P0, R0;                       // vertices <-> trace space
+    std::vector<DevCsr> A, P, R, Dinv;   // per level (Dinv: the inverse diagonal as a matrix for the CSR kernel)
+    std::vector<double*> x, b, r, d;
+    std::vector<double> lmax;
+    std::vector<int> n;
+    DevCsr Cinv;                         // dense pseudo-inverse of the coarsest operator (nrows = 0: smooth only)
+  } amg;
+  AmgHierarchy amg_host;
+  void setup_general_amg() {
+    const Csr P0 = p1_to_trace_matrix(*gtab, *gm);
+    const Csr R0 = csr_transpose(P0);
+    const Csr A0 = csr_multiply(R0, csr_multiply(gops.S, P0));
+    amg_build(A0, amg_host);
+    amg.P0 = upload_csr(P0); amg.R0 = upload_csr(R0);
+    for (size_t l = 0; l < amg_host.lev.size(); l++) {
+      const AmgLevel& L = amg_host.lev[l];
+      const int n = L.A.nrows;
+      amg.n.push_back(n);
+      amg.lmax.push_back(L.lmax);
+      amg.A.push_back(upload_csr(L.A));
+      amg.P.push_back(l + 1 < amg_host.lev.size() ? upload_csr(L.P) : DevCsr());
+      amg.R.push_back(l + 1 < amg_host.lev.size() ? upload_csr(L.R) : DevCsr());
+      Csr D;
+      D.nrows = D.ncols = n;
+      D.rowptr.resize((size_t)n + 1);
+      D.col.resize((size_t)n);
+      for (int i = 0; i <= n; i++) D.rowptr[(size_t)i] = i;
+      for (int i = 0; i < n; i++) D.col[(size_t)i] = i;
+      D.val = L.dinv;
+      amg.Dinv.push_back(upload_csr(D));
+      amg.x.push_back(dalloc(n)); amg.b.push_back(dalloc(n)); amg.r.push_back(dalloc(n)); amg.d.push_back(dalloc(n));
+    }
+    if (amg_host.coarse_pinv.nrows > 0) amg.Cinv = upload_csr(amg_host.coarse_pinv);
+    if (debug_on()) {
+      fprintf(stderr, "[amg] P1 coarse space %d vertices; levels:", amg.n.empty() ? 0 : amg.n[0]);
+      for (size_t l = 0; l < amg.n.size(); l++) fprintf(stderr, " %d (nnz %ld, lmax %.2f)", amg.n[l], amg.A[l].nnz, amg.lmax[l]);
+      fprintf(stderr, "%s\n", amg.Cinv.nrows ? "; dense coarsest solve" : "; coarsest level smoothed only");
+    }
+  }
+  // Chebyshev(2) / Jacobi on level l: x (=, +=) p(D^{-1} A) D^{-1} (b - A x), interval [0.1, 1.1] lambda_max
+  void amg_cheb(int l, bool zero_init) {
+    const int n = amg.n[l];
+    const double lo = 0.1 * amg.lmax[l], hi = 1.1 * amg.lmax[l];
+    const double theta = 0.5 * (hi + lo), delta = 0.5 * (hi - lo), sigma1 = theta / delta, rho = 1.0 / sigma1;
+    const double rn = 1.0 / (2.0 * sigma1 - rho);
+    double* r = amg.r[l];
+    double* d = amg.d[l];
+    copy(r, amg.b[l], n);
+    if (!zero_init) csr(amg.A[l], amg.x[l], -1.0, 1.0, r);        // r0 = b - A x
+    csr(amg.Dinv[l], r, 1.0 / theta, 0.0, d);                     // d0 = Dinv r0 / theta
+    if (zero_init) copy(amg.x[l], d, n); else axpby(n, 1.0, d, 1.0, amg.x[l]);
+    csr(amg.A[l], d, -1.0, 1.0, r);                               // r1 = r0 - A d0
+    csr(amg.Dinv[l], r, 2.0 * rn / delta, rn * rho, d);           // d1 = rn rho d0 + (2 rn / delta) Dinv r1
+    axpby(n, 1.0, d, 1.0, amg.x[l]);
+  }
+  // V-cycle on b[l] -> x[l] (zero initial guess)
+  void amg_vcycle(int l) {
+    const int last = (int)amg.n.size() - 1;
+    if (l == last) {
+      if (amg.Cinv.nrows > 0) csr(amg.Cinv, amg.b[l], 1.0, 0.0, amg.x[l]);
+      else amg_cheb(l, true);
+      return;
+    }
+    amg_cheb(l, true);
+    copy(amg.r[l], amg.b[l], amg.n[l]);
+    csr(amg.A[l], amg.x[l], -1.0, 1.0, amg.r[l]);
+    csr(amg.R[l], amg.r[l], 1.0, 0.0, amg.b[l + 1]);
+    amg_vcycle(l + 1);
+    csr(amg.P[l], amg.x[l + 1], 1.0, 1.0, amg.x[l]);
+    amg_cheb(l, false);
   }
   Engine(const hdg_config& c, Comm* comm_, int nv, const double* coords, int nc, const int* cells) : cfg(c), comm(comm_) {
     if (c.degree < 1 || c.degree > 4) throw std::string("degree must be in 1..4");
@@ -311,7 +397,11 @@ struct Engine {
     NU = n_scalar(K + 1); NP = n_scalar(K); NL = K + 1; NE = K + 2; NX = 2 * NU + NP;
     // solvers of this path: GMRES(m) with the element block-Jacobi, CG with the edge block-Jacobi (the two-level
     // preconditioners of the structured engine lean on the two shared shapes / the vertex grid)
-    cfg.tent_precond = 0; cfg.tent_solver = 0; cfg.trace_precond = 0; cfg.periodic = 0;
+    // trace system: Chebyshev(2) / edge block-Jacobi + the P1 coarse space with an algebraic V-cycle (hdg_amg.hpp);
+    // HDG_GENERAL_NO_COARSE: the edge block-Jacobi alone
+    // tentative velocity: GMRES(30) with the hybrid preconditioner Pi + Dinv (I - Pi) (HDG_GENERAL_BLOCK_JACOBI: Dinv alone)
+    cfg.tent_precond = std::getenv("HDG_GENERAL_BLOCK_JACOBI") ? 0 : 2; cfg.tent_solver = 0; cfg.periodic = 0;
+    cfg.trace_precond = std::getenv("HDG_GENERAL_NO_COARSE") ? 0 : 1;
     cfg.gmres_restart = std::max(cfg.gmres_restart, 30);
     gm = new GMesh();
     gm->build(nv, coords, nc, cells);
@@ -1686,7 +1776,20 @@ struct Engine {
   }
   // z = M r  (tentative-velocity preconditioner)
   void tent_precond(int didx, const double* r, double* z) {
-    if (general) { csr(gdinv[(size_t)didx], r, 1.0, 0.0, z); return; }
+    if (general) {
+      if (cfg.tent_precond == 2) {
+        // hybrid two-level preconditioner Pi + Dinv (I - Pi): the H(div)-conforming part is left alone (mass matrix =
+        // identity), the element block-Jacobi acts on the rest, which carries the normal-jump penalty
+        csr(gd.Pi, r, 1.0, 0.0, wQ3);
+        copy(wQ4, r, NQ);
+        axpby(NQ, -1.0, wQ3, 1.0, wQ4);
+        csr(gdinv[(size_t)didx], wQ4, 1.0, 0.0, z);
+        axpby(NQ, 1.0, wQ3, 1.0, z);
+      } else {
+        csr(gdinv[(size_t)didx], r, 1.0, 0.0, z);
+      }
+      return;
+    }
     if (cfg.tent_precond == 0) {
       blockdiag(dinv0[didx], dinv1[didx], r, nullptr, 0.0, z);
     } else if (cfg.tent_precond == 1) {
@@ -2115,8 +2218,10 @@ struct Engine {
     // round 3: the first step of the zero-start smoother and the prolongation folded into the stencil launches that consume
     // them (HDG_TRACE_NO_FOLD: the separate launches of round 2)
     static const bool fold = !std::getenv("HDG_TRACE_NO_FOLD");
-    if (xc && !(its == 2 && fuse && fold && !periodic)) { p1_to_trace(xc, x, 1.0); xc = nullptr; }
-    if (its == 2 && fuse) {
+    if (general) {
+      if (xc) { csr(amg.P0, xc, 1.0, 1.0, x); xc = nullptr; }
+    } else if (xc && !(its == 2 && fuse && fold && !periodic)) { p1_to_trace(xc, x, 1.0); xc = nullptr; }
+    if (its == 2 && fuse && !general) {
       // two Chebyshev steps in two launches: operator, edge block-Jacobi and update fused (k_trace_smooth)
       const double rn = 1.0 / (2.0 * sigma1 - rho), c2_0 = 1.0 / theta, c1_1 = rn * rho, c2_1 = 2.0 * rn / delta;
       if (zero_init && fold) {
@@ -2348,6 +2453,14 @@ struct Engine {
       fl.set(z, 0); fl.set(w_out, 0);
       return w_out != nullptr;
     }
+    if (general) {
+      cheb_smooth(r, z, true, nsm);
+      trace_apply(z, r, 1.0, -1.0, wL2, 0);
+      csr(amg.R0, wL2, 1.0, 0.0, amg.b[0]);
+      amg_vcycle(0);
+      cheb_smooth(r, z, false, nsm, amg.x[0]);
+      return false;
+    }
     cheb_smooth(r, z, true, nsm);
     trace_apply(z, r, 1.0, -1.0, wL2, 0);  // restricted from owned rows only: no extension
     // restriction to the vertex grid from OWNED edges only (no halo of wL2): the cut rows are completed when the
@@ -2390,8 +2503,9 @@ struct Engine {
       l_to_modal(hL_dev, tr_one);
       HIPCHECK(hipStreamSynchronize(stream));
     }
-    // multigrid hierarchy on the vertex grid
-    if (cfg.trace_precond == 1) {
+    // multigrid hierarchy on the vertex grid (general meshes: algebraic hierarchy of the P1 space)
+    if (cfg.trace_precond == 1 && general) setup_general_amg();
+    else if (cfg.trace_precond == 1) {
       if (comm->size > 1 || std::getenv("HDG_FORCE_RCCL")) mg_gather = dalloc((long)comm->size * (g.ny + 1) * (g.nx + 1));
       int n = g.nx;
       while (true) {

@@ -18,15 +18,49 @@
 // of an edge runs from its lower to its higher vertex number; the fixed edge normal is the right-hand normal of that direction.
 #pragma once
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <exception>
 #include <map>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
 #include "hdg_tables.hpp"
 
 namespace hdg {
+
+// host-side loop over independent cells on the available cores (the per-cell matrices are inverted in extended precision:
+// 9 s on one core for the 32 768-cell disk at k = 2)
+template <class F>
+inline void parallel_for(int n, F&& f) {
+  const unsigned nt = std::min(std::max(1u, std::thread::hardware_concurrency()), 16u);
+  if (n < 256 || nt == 1) {
+    for (int i = 0; i < n; i++) f(i);
+    return;
+  }
+  std::atomic<int> next{0};
+  std::exception_ptr err;
+  std::mutex mtx;
+  std::vector<std::thread> workers;
+  for (unsigned t = 0; t < nt; t++)
+    workers.emplace_back([&]() {
+      try {
+        for (;;) {
+          const int b = next.fetch_add(32);
+          if (b >= n) break;
+          for (int i = b; i < std::min(n, b + 32); i++) f(i);
+        }
+      } catch (...) {
+        std::lock_guard<std::mutex> lk(mtx);
+        if (!err) err = std::current_exception();
+      }
+    });
+  for (auto& w : workers) w.join();
+  if (err) std::rethrow_exception(err);
+}
 
 struct Csr {
   int nrows = 0, ncols = 0;
@@ -405,8 +439,10 @@ inline void assemble_general(const GeneralTables& T, const GMesh& M, GeneralOps&
   const long NQ = (long)nc * n2, NP = (long)nc * np, NL = (long)nE * nl;
   if (NQ >= (1L << 31) || (long)nc * n * n >= (1L << 40)) throw std::string("general mesh too large");
   loc.resize((size_t)nc);
-  for (int c = 0; c < nc; c++) cell_edge_blocks(T, M, c, loc[(size_t)c]);
-  for (int c = 0; c < nc; c++) cell_matrices(T, M, c, T.tau, loc[(size_t)c]);
+  parallel_for(nc, [&](int c) {
+    cell_edge_blocks(T, M, c, loc[(size_t)c]);
+    cell_matrices(T, M, c, T.tau, loc[(size_t)c]);
+  });
   CsrBuilder Pi((int)NQ, (int)NQ), Wd((int)NP, (int)NQ), Bd((int)NP, (int)NQ), Gp((int)NQ, (int)NP), Gl((int)NQ, (int)NL),
       Yw((int)NL, (int)NQ), Yp((int)NL, (int)NP), S((int)NL, (int)NL), Auu((int)NQ, (int)NQ), Aup((int)NQ, (int)NP),
       Apu((int)NP, (int)NQ), App((int)NP, (int)NP), Wu((int)NQ, (int)NL), Wp((int)NP, (int)NL), Rq((int)NL, (int)NQ),
@@ -559,7 +595,7 @@ inline void assemble_general(const GeneralTables& T, const GMesh& M, GeneralOps&
 inline Csr assemble_block_jacobi(const GeneralTables& T, const GMesh& M, const std::vector<CellLocal>& loc, double gamma) {
   const int n2 = T.n2, ne = T.ne;
   CsrBuilder D(M.nc * n2, M.nc * n2);
-  for (int c = 0; c < M.nc; c++) {
+  parallel_for(M.nc, [&](int c) {  // rows of different cells: disjoint parts of the builder
     std::vector<real> Dm((size_t)n2 * n2, 0);
     for (int i = 0; i < n2; i++) Dm[(size_t)i * n2 + i] = 1;
     for (int l = 0; l < 3; l++) {
@@ -572,7 +608,7 @@ inline Csr assemble_block_jacobi(const GeneralTables& T, const GMesh& M, const s
     invert(n2, Dm);
     for (int r = 0; r < n2; r++)
       for (int cc = 0; cc < n2; cc++) D.add(c * n2 + r, c * n2 + cc, (double)Dm[(size_t)r * n2 + cc]);
-  }
+  });
   return D.build();
 }
 

@@ -17,16 +17,27 @@ struct DevCsr {
   const int* rowptr = nullptr;
   const int* col = nullptr;
   const double* val = nullptr;
+  int tpr = 1;  // threads per row of k_csr_apply (a power of two <= 64, from the average row length)
 };
 
-// y = beta * y + alpha * A x      (one thread per row; rows hold 10 .. 300 entries)
-__global__ void k_csr_apply(DevCsr A, const double* __restrict__ x, double alpha, double beta, double* __restrict__ y) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= A.nrows) return;
+// y = beta * y + alpha * A x.  T threads share a row (rows hold 1 .. 300 entries): consecutive lanes read consecutive
+// entries, so a wave's loads of val / col coalesce; the partial sums are combined by shuffles in a fixed order (deterministic).
+// (One thread per row made every lane walk its own row: 163 us per launch on average on the 32 768-cell disk, 95 % of a step.)
+template <int T>
+__global__ __launch_bounds__(256) void k_csr_apply(DevCsr A, const double* __restrict__ x, double alpha, double beta,
+                                                   double* __restrict__ y) {
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long r = gid / T;
+  const int lane = (int)(gid % T);
+  const bool live = r < A.nrows;
   double acc = 0.0;
-  const int b = A.rowptr[r], e = A.rowptr[r + 1];
-  for (int q = b; q < e; q++) acc = fma(A.val[q], x[A.col[q]], acc);
-  y[r] = beta == 0.0 ? alpha * acc : fma(alpha, acc, beta * y[r]);
+  if (live) {
+    const int b = A.rowptr[r], e = A.rowptr[r + 1];
+    for (int q = b + lane; q < e; q += T) acc = fma(A.val[q], x[A.col[q]], acc);
+  }
+#pragma unroll
+  for (int off = T / 2; off > 0; off >>= 1) acc += __shfl_down(acc, off, T);
+  if (live && lane == 0) y[r] = beta == 0.0 ? alpha * acc : fma(alpha, acc, beta * y[r]);
 }
 
 struct GGeo {

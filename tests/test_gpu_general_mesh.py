@@ -197,3 +197,38 @@ def test_driver_runs_kelvin_helmholtz(hip_lib, capsys, tmp_path):
     out = capsys.readouterr().out
     assert "model problem = kelvinhelmholtz" in out and "refinement level = 1" in out
     assert (tmp_path / "solution.pvd").exists()
+
+
+def test_general_mesh_preconditioners_are_mesh_independent(hip_lib, monkeypatch):
+    """The two-level preconditioners of the general path (hdg_amg.hpp; hdg_imex.py:139-167 GTMG + GAMG, :224-228 for the
+    tentative velocity): the P1 coarse space with its algebraic V-cycle keeps the CG count of the condensed system bounded
+    under refinement of the disk, the edge block-Jacobi alone doubles it per level; the hybrid preconditioner of the
+    tentative velocity at least halves the GMRES count of the element block-Jacobi; and none of them changes the answer."""
+    from incompressibleeulerhdg_amd.mesh import UnitDiskMesh
+    from incompressibleeulerhdg_amd.model_problems import KelvinHelmholtz
+    from incompressibleeulerhdg_amd.timesteppers import IncompressibleEulerHDGIMEXSSP2_332
+
+    def run(level, k, env):
+        for name in ("HDG_GENERAL_NO_COARSE", "HDG_GENERAL_BLOCK_JACOBI"):
+            monkeypatch.delenv(name, raising=False)
+        for name in env:
+            monkeypatch.setenv(name, "1")
+        ts = IncompressibleEulerHDGIMEXSSP2_332(UnitDiskMesh(level), k, 0.005, use_projection_method=True, n_richardson=2)
+        kh = KelvinHelmholtz(ts._V_Q, ts._V_p)
+        Q, p = ts.solve(*kh.initial_condition(), None, kh.f_rhs(), 0.01, fused=True)
+        sums, cnt = ts._engine.iteration_stats()
+        return Q.dat.data.copy(), p.dat.data.copy(), sums / cnt
+
+    its = {}
+    for level in (2, 3, 4):
+        Q1, p1, its[level, "two-level"] = run(level, 1, ())
+        Q0, p0, its[level, "one-level"] = run(level, 1, ("HDG_GENERAL_NO_COARSE", "HDG_GENERAL_BLOCK_JACOBI"))
+        assert _rel(Q1, Q0) < TOL and np.max(np.abs(p1 - p0)) < TOL * max(np.max(np.abs(p0)), 1.0)
+    cg = lambda level, which: its[level, which][1]      # tentative, pressure, final pressure, reconstruction
+    gm = lambda level, which: its[level, which][0]
+    assert cg(4, "two-level") < 20 and cg(4, "two-level") < cg(2, "two-level") + 8
+    assert cg(4, "one-level") > 3.0 * cg(2, "one-level") and cg(4, "one-level") > 8 * cg(4, "two-level")
+    assert gm(4, "two-level") < 0.5 * gm(4, "one-level")
+    # k = 2: same behaviour
+    _, _, i2 = run(3, 2, ())
+    assert i2[1] < 20
