@@ -2418,14 +2418,15 @@ struct Engine {
       auto launch = [&](auto kk) {
         constexpr int KK = decltype(kk)::value;
         typedef TraceTile<KK> TT;
-        const dim3 grid((g.nx + 1 + TT::TW - 1) / TT::TW, (g.ny + 1 + TT::TH - 1) / TT::TH);
+        const int ntx = (g.nx + 1 + TT::TW - 1) / TT::TW, nty = (g.ny + 1 + TT::TH - 1) / TT::TH;
+        const int grid = 8 * ((ntx * nty + 7) / 8);  // XCD-aware tile order (hdg_trace_tile.hpp: HDG_TILE_OF_BLOCK)
         tally(LC_TRACE_SMOOTH, 3 * bL());
-        k_trace_pre_tile<KK><<<grid, TT::NTHREADS, 0, stream>>>(g, pdt(), r, c0, c1, c2, ch_d, wL2);
+        k_trace_pre_tile<KK><<<grid, TT::NTHREADS, 0, stream>>>(ntx, nty, g, pdt(), r, c0, c1, c2, ch_d, wL2);
         tally(LC_MG, bL() + nvtx);
         k_trace_to_p1<<<corner_grid_all(), bs(), 0, stream>>>(g_all, NL, wL2, mg_b[0], dt.elen[0], dt.elen[2], dt.elen[1], 0);
         run_vcycle();
         tally(LC_TRACE_SMOOTH, (w_out ? 4 : 3) * bL() + nvtx);
-        const long nblk = (long)grid.x * grid.y;
+        const long nblk = (long)ntx * nty;
         double* part = nullptr;
         static const bool no_fused_dots = getenv("HDG_TRACE_NO_FUSED_DOTS") != nullptr;
         if (w_out && dots_out && !no_fused_dots) {
@@ -2433,10 +2434,10 @@ struct Engine {
           part = tile_part;
         }
         if (part)
-          k_trace_post_tile<KK, true><<<grid, TT::NTHREADS, 0, stream>>>(g, pdt(), ch_d, r, mg_x[0], std::sqrt(dt.elen[0]), std::sqrt(dt.elen[2]),
+          k_trace_post_tile<KK, true><<<grid, TT::NTHREADS, 0, stream>>>(ntx, nty, g, pdt(), ch_d, r, mg_x[0], std::sqrt(dt.elen[0]), std::sqrt(dt.elen[2]),
                                                                          std::sqrt(dt.elen[1]), c0, c1, c2, z, w_out, part);
         else
-          k_trace_post_tile<KK, false><<<grid, TT::NTHREADS, 0, stream>>>(g, pdt(), ch_d, r, mg_x[0], std::sqrt(dt.elen[0]), std::sqrt(dt.elen[2]),
+          k_trace_post_tile<KK, false><<<grid, TT::NTHREADS, 0, stream>>>(ntx, nty, g, pdt(), ch_d, r, mg_x[0], std::sqrt(dt.elen[0]), std::sqrt(dt.elen[2]),
                                                                           std::sqrt(dt.elen[1]), c0, c1, c2, z, w_out, nullptr);
         if (part) {
           tally(LC_OTHER, 0.0);
