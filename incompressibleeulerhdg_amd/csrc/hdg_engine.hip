@@ -264,8 +264,8 @@ struct Engine {
   GeneralTables* gtab = nullptr;
   GeneralOps gops;
   std::vector<CellLocal> gloc;
-  struct GDev {
-    DevCsr Pi, Wdiv, Bdiv, Gp, Gl, Yw, Yp, S, Auu, Aup, Apu, App, Wu, Wp, Dtr, Rq, Rp, Rb, Cq, Cqi, Cp, Cpi, Cl, Cli;
+  struct GDev {  // operators that do not depend on the stabilisation parameter
+    DevCsr Pi, Wdiv, Bdiv, Gp, Gl, Rq, Rp, Rb, Cq, Cqi, Cp, Cpi, Cl, Cli, Psi_p, Psi_l, Mu_u, Mu_p, Mu_l;
   } gd;
   std::vector<DevCsr> gdinv;  // element block-Jacobi per stage
   GGeo ggeo;
@@ -311,12 +311,25 @@ struct Engine {
     std::vector<double> lmax;
     std::vector<int> n;
     DevCsr Cinv;                         // dense pseudo-inverse of the coarsest operator (nrows = 0: smooth only)
-  } amg;
-  AmgHierarchy amg_host;
-  void setup_general_amg() {
+  };
+  // operators that depend on the stabilisation parameter tau: one set per PSet (psets[i] <-> gsets[i]; the second set,
+  // tau' = tau / gamma, belongs to the block preconditioner of the monolithic solve, section 7 of DESIGN.md)
+  struct GSet {
+    DevCsr S, Dtr, Yw, Yp, Wu, Wp, Auu, Aup, Apu, App;
+    AmgDev amg;
+  };
+  std::vector<GSet> gsets;
+  GSet& gs() { return gsets[(size_t)cur_pset]; }
+  void upload_gset(const GeneralOps& O, GSet& G) {
+    G.S = upload_csr(O.S); G.Dtr = upload_csr(O.Dtr); G.Yw = upload_csr(O.Yw); G.Yp = upload_csr(O.Yp);
+    G.Wu = upload_csr(O.Wu); G.Wp = upload_csr(O.Wp); G.Auu = upload_csr(O.Auu); G.Aup = upload_csr(O.Aup);
+    G.Apu = upload_csr(O.Apu); G.App = upload_csr(O.App);
+  }
+  void setup_general_amg(const Csr& S_host, AmgDev& amg) {
+    AmgHierarchy amg_host;
     const Csr P0 = p1_to_trace_matrix(*gtab, *gm);
     const Csr R0 = csr_transpose(P0);
-    const Csr A0 = csr_multiply(R0, csr_multiply(gops.S, P0));
+    const Csr A0 = csr_multiply(R0, csr_multiply(S_host, P0));
     amg_build(A0, amg_host);
     amg.P0 = upload_csr(P0); amg.R0 = upload_csr(R0);
     for (size_t l = 0; l < amg_host.lev.size(); l++) {
@@ -346,6 +359,7 @@ struct Engine {
   }
   // Chebyshev(2) / Jacobi on level l: x (=, +=) p(D^{-1} A) D^{-1} (b - A x), interval [0.1, 1.1] lambda_max
   void amg_cheb(int l, bool zero_init) {
+    AmgDev& amg = gs().amg;
     const int n = amg.n[l];
     const double lo = 0.1 * amg.lmax[l], hi = 1.1 * amg.lmax[l];
     const double theta = 0.5 * (hi + lo), delta = 0.5 * (hi - lo), sigma1 = theta / delta, rho = 1.0 / sigma1;
@@ -362,6 +376,7 @@ struct Engine {
   }
   // V-cycle on b[l] -> x[l] (zero initial guess)
   void amg_vcycle(int l) {
+    AmgDev& amg = gs().amg;
     const int last = (int)amg.n.size() - 1;
     if (l == last) {
       if (amg.Cinv.nrows > 0) csr(amg.Cinv, amg.b[l], 1.0, 0.0, amg.x[l]);
@@ -381,7 +396,6 @@ struct Engine {
     if (c.nstages < 1 || c.nstages > HDG_MAX_STAGES) throw std::string("nstages out of range");
     if (!(c.dt > 0)) throw std::string("dt must be positive");
     if (comm->size != 1) throw std::string("general meshes are implemented for a single rank");
-    if (!c.use_projection) throw std::string("general meshes: the projection method only (no monolithic solve)");
     HIPCHECK(hipSetDevice(c.device));
     HIPCHECK(hipStreamCreate(&stream));
     try {
@@ -420,9 +434,11 @@ struct Engine {
     alloc_state();
     // device copies
     gd.Pi = upload_csr(gops.Pi); gd.Wdiv = upload_csr(gops.Wdiv); gd.Bdiv = upload_csr(gops.Bdiv); gd.Gp = upload_csr(gops.Gp);
-    gd.Gl = upload_csr(gops.Gl); gd.Yw = upload_csr(gops.Yw); gd.Yp = upload_csr(gops.Yp); gd.S = upload_csr(gops.S);
-    gd.Auu = upload_csr(gops.Auu); gd.Aup = upload_csr(gops.Aup); gd.Apu = upload_csr(gops.Apu); gd.App = upload_csr(gops.App);
-    gd.Wu = upload_csr(gops.Wu); gd.Wp = upload_csr(gops.Wp); gd.Dtr = upload_csr(gops.Dtr); gd.Rq = upload_csr(gops.Rq);
+    gd.Gl = upload_csr(gops.Gl); gd.Rq = upload_csr(gops.Rq);
+    gsets.emplace_back();
+    upload_gset(gops, gsets[0]);
+    gd.Psi_p = upload_csr(gops.Psi_p); gd.Psi_l = upload_csr(gops.Psi_l); gd.Mu_u = upload_csr(gops.Mu_u);
+    gd.Mu_p = upload_csr(gops.Mu_p); gd.Mu_l = upload_csr(gops.Mu_l);
     gd.Rp = upload_csr(gops.Rp); gd.Rb = upload_csr(gops.Rb); gd.Cq = upload_csr(gops.Cq); gd.Cqi = upload_csr(gops.Cqi);
     gd.Cp = upload_csr(gops.Cp); gd.Cpi = upload_csr(gops.Cpi); gd.Cl = upload_csr(gops.Cl); gd.Cli = upload_csr(gops.Cli);
     d_one_p = upload(gops.one_p); d_int_p = upload(gops.int_p); d_one_l = upload(gops.one_l);
@@ -1326,8 +1342,8 @@ struct Engine {
   }
   void trace_apply(const double* lam, const double* base, double cb, double ct, double* out, int max_ext = GH) {
     if (general) {
-      if (base && cb != 0.0) { if (out != base) copy(out, base, NLv); if (cb != 1.0) axpby(NLv, 0.0, out, cb, out); csr(gd.S, lam, ct, 1.0, out); }
-      else csr(gd.S, lam, ct, 0.0, out);
+      if (base && cb != 0.0) { if (out != base) copy(out, base, NLv); if (cb != 1.0) axpby(NLv, 0.0, out, cb, out); csr(gs().S, lam, ct, 1.0, out); }
+      else csr(gs().S, lam, ct, 0.0, out);
       return;
     }
     tally(LC_TRACE_APPLY, bL() * (2 + ((base && cb != 0.0) ? 1 : 0)));
@@ -1367,7 +1383,7 @@ struct Engine {
   }
   void trace_cheb(const double* r, double* d, double* x, double c1, double c2, bool assign = false) {
     if (general) {
-      csr(gd.Dtr, r, c2, c1, d);  // d = c1 d + c2 Dinv r
+      csr(gs().Dtr, r, c2, c1, d);  // d = c1 d + c2 Dinv r
       if (x) { if (assign) copy(x, d, NLv); else axpby(NLv, 1.0, d, 1.0, x); }
       return;
     }
@@ -1390,8 +1406,8 @@ struct Engine {
   void condense(const double* rw, const double* rp, const double* rl, double* out) {
     if (general) {
       if (rl) axpby(NLv, -1.0, rl, 0.0, out); else zero(out, NLv);
-      if (rw) csr(gd.Yw, rw, 1.0, 1.0, out);
-      if (rp) csr(gd.Yp, rp, 1.0, 1.0, out);
+      if (rw) csr(gs().Yw, rw, 1.0, 1.0, out);
+      if (rp) csr(gs().Yp, rp, 1.0, 1.0, out);
       return;
     }
     if (rw) halo_Q(rw);
@@ -1423,10 +1439,10 @@ struct Engine {
   }
   void backsub(const double* rw, const double* rp, const double* lam, double* u, double* phi) {
     if (general) {
-      csr(gd.Wu, lam, 1.0, 0.0, u);    // Wu = -W
-      csr(gd.Wp, lam, 1.0, 0.0, phi);
-      if (rw) { csr(gd.Auu, rw, 1.0, 1.0, u); csr(gd.Apu, rw, 1.0, 1.0, phi); }
-      if (rp) { csr(gd.Aup, rp, 1.0, 1.0, u); csr(gd.App, rp, 1.0, 1.0, phi); }
+      csr(gs().Wu, lam, 1.0, 0.0, u);    // Wu = -W
+      csr(gs().Wp, lam, 1.0, 0.0, phi);
+      if (rw) { csr(gs().Auu, rw, 1.0, 1.0, u); csr(gs().Apu, rw, 1.0, 1.0, phi); }
+      if (rp) { csr(gs().Aup, rp, 1.0, 1.0, u); csr(gs().App, rp, 1.0, 1.0, phi); }
       return;
     }
     halo_L(lam);
@@ -1453,13 +1469,27 @@ struct Engine {
     else { HDG_DISPATCH(k_backsub<KK, true, true><<<cell_grid(), bs(), 0, stream>>>(g, pdt(), rw, rp, lam, u, phi)); }
   }
   void gamma_psi(const double* u, const double* phi, const double* lam, double* out) {
-    if (general) general_unsupported("the monolithic (unsplit) solve");
+    if (general) {
+      double beta = 0.0;
+      if (u) { csr(gd.Bdiv, u, 1.0, beta, out); beta = 1.0; }
+      if (phi) { csr(gd.Psi_p, phi, 1.0, beta, out); beta = 1.0; }
+      if (lam) { csr(gd.Psi_l, lam, 1.0, beta, out); beta = 1.0; }
+      if (beta == 0.0) zero(out, NPv);
+      return;
+    }
     if (lam) halo_L(lam);
     tally(LC_OTHER, (u ? bQ() : 0.0) + (phi ? bP() : 0.0) + (lam ? bL() : 0.0) + bP());
     HDG_DISPATCH(k_gamma_psi<KK><<<cell_grid(), bs(), 0, stream>>>(g, dt, u, phi, lam, out));
   }
   void gamma_mu(const double* u, const double* phi, const double* lam, double* out) {
-    if (general) general_unsupported("the monolithic (unsplit) solve");
+    if (general) {
+      double beta = 0.0;
+      if (u) { csr(gd.Mu_u, u, 1.0, beta, out); beta = 1.0; }
+      if (phi) { csr(gd.Mu_p, phi, 1.0, beta, out); beta = 1.0; }
+      if (lam) { csr(gd.Mu_l, lam, 1.0, beta, out); beta = 1.0; }
+      if (beta == 0.0) zero(out, NLv);
+      return;
+    }
     if (u) halo_Q(u);
     if (phi) halo_P(phi);
     tally(LC_OTHER, (u ? bQ() : 0.0) + (phi ? bP() : 0.0) + bL() * (lam ? 2 : 1));
@@ -2219,7 +2249,7 @@ struct Engine {
     // them (HDG_TRACE_NO_FOLD: the separate launches of round 2)
     static const bool fold = !std::getenv("HDG_TRACE_NO_FOLD");
     if (general) {
-      if (xc) { csr(amg.P0, xc, 1.0, 1.0, x); xc = nullptr; }
+      if (xc) { csr(gs().amg.P0, xc, 1.0, 1.0, x); xc = nullptr; }
     } else if (xc && !(its == 2 && fuse && fold && !periodic)) { p1_to_trace(xc, x, 1.0); xc = nullptr; }
     if (its == 2 && fuse && !general) {
       // two Chebyshev steps in two launches: operator, edge block-Jacobi and update fused (k_trace_smooth)
@@ -2457,9 +2487,9 @@ struct Engine {
     if (general) {
       cheb_smooth(r, z, true, nsm);
       trace_apply(z, r, 1.0, -1.0, wL2, 0);
-      csr(amg.R0, wL2, 1.0, 0.0, amg.b[0]);
+      csr(gs().amg.R0, wL2, 1.0, 0.0, gs().amg.b[0]);
       amg_vcycle(0);
-      cheb_smooth(r, z, false, nsm, amg.x[0]);
+      cheb_smooth(r, z, false, nsm, gs().amg.x[0]);
       return false;
     }
     cheb_smooth(r, z, true, nsm);
@@ -2505,7 +2535,7 @@ struct Engine {
       HIPCHECK(hipStreamSynchronize(stream));
     }
     // multigrid hierarchy on the vertex grid (general meshes: algebraic hierarchy of the P1 space)
-    if (cfg.trace_precond == 1 && general) setup_general_amg();
+    if (cfg.trace_precond == 1 && general) setup_general_amg(gops.S, gsets[0].amg);
     else if (cfg.trace_precond == 1) {
       if (comm->size > 1 || std::getenv("HDG_FORCE_RCCL")) mg_gather = dalloc((long)comm->size * (g.ny + 1) * (g.nx + 1));
       int n = g.nx;
@@ -2551,6 +2581,19 @@ struct Engine {
   int get_pset(double tau_) {
     for (size_t i = 0; i < psets.size(); i++)
       if (std::fabs(psets[i].tau - tau_) <= 1e-14 * std::fabs(tau_)) return (int)i;
+    if (general) {
+      // a second set of the tau-dependent operators (and its own coarse hierarchy), assembled like the first
+      GeneralTables t2(K, tau_, cfg.alpha_penalty, cfg.equispaced_nodes);
+      GeneralOps o2;
+      std::vector<CellLocal> l2;
+      assemble_general(t2, *gm, o2, l2);
+      gsets.emplace_back();
+      upload_gset(o2, gsets.back());
+      if (cfg.trace_precond == 1) setup_general_amg(o2.S, gsets.back().amg);
+      psets.push_back(PSet{dt, 0.0, 0.0, tau_});
+      estimate_cheb((int)psets.size() - 1);
+      return (int)psets.size() - 1;
+    }
     PSet ps{dt, 0.0, 0.0, tau_};
     dvec SKh[2];
     for (int sh = 0; sh < 2; sh++) {

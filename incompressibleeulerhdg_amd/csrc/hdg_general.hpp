@@ -428,6 +428,10 @@ inline void cell_matrices(const GeneralTables& T, const GMesh& M, int c, double 
 // ------------------------------------------------------------------------------------------
 struct GeneralOps {
   Csr Pi, Wdiv, Bdiv, Gp, Gl, Yw, Yp, S, Auu, Aup, Apu, App, Wu, Wp, Dtr, Rq, Rp, Rb;
+  // constraint rows Gamma of the monolithic system (hdg_imex.py:342-351; k_gamma_psi / k_gamma_mu of the structured engine):
+  //   psi-row  B u + Psi_p phi + Psi_l lambda,  Psi_p = tau sum_e Pt_e^T Pt_e,  Psi_l = -tau Pt_e^T       (B = Bdiv)
+  //   mu-row   Mu_u u + Mu_p phi + Mu_l lambda, Mu_u = sigma N_e, Mu_p = tau Pt_e, Mu_l = -tau (cells of the edge) I
+  Csr Psi_p, Psi_l, Mu_u, Mu_p, Mu_l;
   Csr Cq, Cqi, Cp, Cpi, Cl, Cli;
   dvec one_p, int_p, one_l;  // coefficients of the constant 1 (pressure, trace), integrals of the pressure basis functions
   dvec xq, xp;               // node coordinates (boundary layout)
@@ -446,7 +450,8 @@ inline void assemble_general(const GeneralTables& T, const GMesh& M, GeneralOps&
   CsrBuilder Pi((int)NQ, (int)NQ), Wd((int)NP, (int)NQ), Bd((int)NP, (int)NQ), Gp((int)NQ, (int)NP), Gl((int)NQ, (int)NL),
       Yw((int)NL, (int)NQ), Yp((int)NL, (int)NP), S((int)NL, (int)NL), Auu((int)NQ, (int)NQ), Aup((int)NQ, (int)NP),
       Apu((int)NP, (int)NQ), App((int)NP, (int)NP), Wu((int)NQ, (int)NL), Wp((int)NP, (int)NL), Rq((int)NL, (int)NQ),
-      Rp((int)NL, (int)NP), Rb((int)NL, (int)NQ);
+      Rp((int)NL, (int)NP), Rb((int)NL, (int)NQ), Psp((int)NP, (int)NP), Psl((int)NP, (int)NL), Muu((int)NL, (int)NQ),
+      Mup((int)NL, (int)NP), Mul((int)NL, (int)NL);
   for (int c = 0; c < nc; c++) {
     const CellLocal& L = loc[(size_t)c];
     const int q0 = c * n2, p0 = c * np;
@@ -493,6 +498,17 @@ inline void assemble_general(const GeneralTables& T, const GMesh& M, GeneralOps&
       // pressure gradient: - sigma N_e^T lambda_e
       for (int a = 0; a < nl; a++)
         for (int cc = 0; cc < n2; cc++) Gl.add(q0 + cc, l0 + a, (double)(-sg * L.N[l][(size_t)a * n2 + cc]));
+      // constraint rows of the monolithic system
+      for (int a = 0; a < nl; a++) {
+        for (int cc = 0; cc < n2; cc++) Muu.add(l0 + a, q0 + cc, (double)(sg * L.N[l][(size_t)a * n2 + cc]));
+        for (int m = 0; m < np; m++) {
+          const double ev = T.tau * (double)L.Pt[l][(size_t)a * np + m];
+          Mup.add(l0 + a, p0 + m, ev);
+          Psl.add(p0 + m, l0 + a, -ev);
+          for (int m2 = 0; m2 < np; m2++) Psp.add(p0 + m, p0 + m2, T.tau * (double)(L.Pt[l][(size_t)a * np + m] * L.Pt[l][(size_t)a * np + m2]));
+        }
+        Mul.add(l0 + a, l0 + a, -T.tau);
+      }
       // condensation, condensed operator, back-substitution
       for (int a = 0; a < nl; a++) {
         for (int cc = 0; cc < n2; cc++) Yw.add(l0 + a, q0 + cc, (double)L.Y[(size_t)(l * nl + a) * n + cc]);
@@ -528,6 +544,7 @@ inline void assemble_general(const GeneralTables& T, const GMesh& M, GeneralOps&
   O.Pi = Pi.build(); O.Wdiv = Wd.build(); O.Bdiv = Bd.build(); O.Gp = Gp.build(); O.Gl = Gl.build();
   O.Yw = Yw.build(); O.Yp = Yp.build(); O.S = S.build(); O.Auu = Auu.build(); O.Aup = Aup.build(); O.Apu = Apu.build();
   O.App = App.build(); O.Wu = Wu.build(); O.Wp = Wp.build(); O.Rq = Rq.build(); O.Rp = Rp.build(); O.Rb = Rb.build();
+  O.Psi_p = Psp.build(); O.Psi_l = Psl.build(); O.Mu_u = Muu.build(); O.Mu_p = Mup.build(); O.Mu_l = Mul.build();
   // edge block-Jacobi of -S
   {
     CsrBuilder D((int)NL, (int)NL);

@@ -3,7 +3,7 @@
     python -m incompressibleeulerhdg_amd.driver --nx 64 --degree 2 --use_projection_method
 
 ``--problem taylorgreen`` (unit square), ``--problem shear`` (doubly periodic square, driver.py:182-183) and
-``--problem kelvinhelmholtz`` (UnitDiskMesh(refinement), driver.py:184-185: the general-mesh path, projection method only)
+``--problem kelvinhelmholtz`` (UnitDiskMesh(refinement), driver.py:184-185: the general-mesh path, projection and monolithic)
 are built; the ``conforming`` / ``dg`` discretisations raise.  ``--animation`` (evolution.pvd with
 the CG vorticity, callbacks.py:30-85) and ``--tracer_advection`` (driver.py:340-344) work on the two square meshes.  The final fields are written to ``solution.pvd``
 (``--output``) like the reference does (driver.py:356-385).
@@ -75,10 +75,6 @@ def main(argv=None):
         mesh = PeriodicSquareMesh(args.nx, args.nx, L=2 * np.pi, quadrilateral=False)  # driver.py:182-183
     elif args.problem == "kelvinhelmholtz":
         mesh = UnitDiskMesh(refinement_level=args.refinement)  # driver.py:184-185
-        if args.timestepper == "implicit" and not args.use_projection_method:
-            raise RuntimeError("general meshes: the projection method only (add --use_projection_method)")
-        if not args.use_projection_method:
-            raise RuntimeError("general meshes: the projection method only (add --use_projection_method)")
     else:
         mesh = UnitSquareMesh(args.nx, args.nx, quadrilateral=False)  # driver.py:181
     if args.timestepper == "implicit":

@@ -250,5 +250,31 @@ def test_general_mesh_fully_implicit_stepper(hip_lib, kind, k):
     ts = IncompressibleEulerHDGImplicit(pm, k, dt, flux="upwind", use_projection_method=True, n_richardson=2)
     Q, p = ts.solve(Q0, p0, None, f, 2 * dt)
     assert _rel(Q.dat.data, oQ) < TOL and _rel(p.dat.data, op) < TOL
-    with pytest.raises(Exception, match="projection method only"):
-        IncompressibleEulerHDGImplicit(pm, k, dt, use_projection_method=False).solve(Q0, p0, None, f, dt)
+
+
+@pytest.mark.parametrize("kind,k,stepper", [("disk1", 1, "implicit"), ("irregular", 2, "implicit"), ("disk1", 2, "imex_ssp2_332"),
+                                            ("square4", 1, "imex_ars3_443")])
+def test_general_mesh_monolithic_solves(hip_lib, kind, k, stepper):
+    """use_projection_method=False -- the reference driver's DEFAULT (driver.py:97-102) -- on a general triangulation: the
+    monolithic (u, phi, lambda) stage system (hdg_imex.py:600-620, hdg_implicit.py:151-186) through flexible GMRES with the
+    block preconditioner (a second set of tau-dependent operators and its own coarse hierarchy), against the oracle's
+    bordered sparse LU."""
+    from incompressibleeulerhdg_amd import timesteppers as ts_mod
+    from oracle import hdg_oracle as orc
+
+    pm, om = _mesh(kind)
+    dt = 0.02
+    Q0, p0, f = _smooth(31 + k)
+    d = orc.HDGDiscretisation(0, k, mesh=om)
+    fo = lambda t: d.interpolate_velocity(f(t))
+    if stepper == "implicit":
+        oQ, op = orc.OracleHDGImplicit(d, dt, use_projection_method=False).solve(d.interpolate_velocity(Q0), d.interpolate_pressure(p0), fo, 2 * dt)
+        ts = ts_mod.IncompressibleEulerHDGImplicit(pm, k, dt, use_projection_method=False)
+    else:
+        oQ, op = orc.OracleHDGIMEX(d, dt, stepper, use_projection_method=False).solve(d.interpolate_velocity(Q0), d.interpolate_pressure(p0), fo, 2 * dt)
+        cls = {"imex_ssp2_332": ts_mod.IncompressibleEulerHDGIMEXSSP2_332, "imex_ars3_443": ts_mod.IncompressibleEulerHDGIMEXARS3_443}[stepper]
+        ts = cls(pm, k, dt, use_projection_method=False)
+    Q, p = ts.solve(Q0, p0, None, f, 2 * dt)
+    assert _rel(Q.dat.data, oQ) < TOL and _rel(p.dat.data, op) < TOL
+    sums, cnt = ts._engine.iteration_stats()
+    assert np.all(sums[cnt > 0] / cnt[cnt > 0] < 200)
