@@ -513,6 +513,7 @@ struct Engine {
     tab = nullptr;
     delete gm; gm = nullptr;
     delete gtab; gtab = nullptr;
+    delete gcg; gcg = nullptr;
   }
   void construct(const hdg_config& c) {
     K = c.degree;
@@ -3061,9 +3062,23 @@ struct Engine {
   double *cg_y = nullptr, *cg_b = nullptr, *cg_x = nullptr, *cg_rr = nullptr, *cg_zz = nullptr, *cg_pp = nullptr, *cg_Ap2 = nullptr,
          *cg_dinv = nullptr, *uproj = nullptr;
   int cg_its_last = 0;
+  GeneralCG* gcg = nullptr;
+  struct { DevCsr M, Bp[2], Ep[2], Vort, R; } gcgd;
   void cg_setup() {
-    if (general) general_unsupported("the continuous space (tracer, vorticity)");
     if (cg_ready) return;
+    if (general) {  // host-assembled operators of the continuous space (hdg_general.hpp: assemble_cg)
+      gcg = new GeneralCG();
+      assemble_cg(*gtab, *gm, gops, *gcg);
+      std::memset(&cgt, 0, sizeof(cgt));
+      cgt.p = K + 1; cgt.ncg = gcg->ncg;
+      gcgd.M = upload_csr(gcg->M); gcgd.Vort = upload_csr(gcg->Vort); gcgd.R = upload_csr(gcg->R);
+      for (int d = 0; d < 2; d++) { gcgd.Bp[d] = upload_csr(gcg->Bp[d]); gcgd.Ep[d] = upload_csr(gcg->Ep[d]); }
+      for (double** v : {&cg_b, &cg_x, &cg_rr, &cg_zz, &cg_pp, &cg_Ap2}) *v = dalloc(cgt.ncg);
+      cg_dinv = const_cast<double*>(upload(gcg->diag));  // the diagonal itself (k_pointwise_div divides by it)
+      uproj = dalloc(NQ);
+      cg_ready = true;
+      return;
+    }
     if (comm->size > 1) throw std::string("the continuous space (tracer, vorticity) is implemented for a single rank");
     const int p = K + 1;
     std::vector<real> xi, eta;
@@ -3166,6 +3181,7 @@ struct Engine {
     }
   }
   void cg_mass(const double* c_in, double* out) {  // out = M_CG c_in
+    if (general) { csr(gcgd.M, c_in, 1.0, 0.0, out); return; }
     HDG_DISPATCH(k_cg_cell<KK, 0><<<cell_grid(), bs(), 0, stream>>>(g, cgt, dt, cg_Mloc, dt.Vuinv, nullptr, nullptr, nullptr, nullptr,
                                                                      nullptr, c_in, nullptr, 0, cg_y));
     HDG_DISPATCH(k_cg_gather<KK><<<corner_grid_all(), bs(), 0, stream>>>(g_all, cgt, cg_y, out));
@@ -3210,6 +3226,14 @@ struct Engine {
   // L2 projection of a broken velocity onto [CG_{k+1}]^2 (common.py:119-122); result as a broken modal vector
   void cg_project(const double* vel_in, double* vel_out) {
     cg_setup();
+    if (general) {
+      for (int d = 0; d < 2; d++) {
+        csr(gcgd.Bp[d], vel_in, 1.0, 0.0, cg_b);
+        cg_solve();
+        csr(gcgd.Ep[d], cg_x, 1.0, d == 0 ? 0.0 : 1.0, vel_out);  // component 0 clears the rows of component 1, which then adds
+      }
+      return;
+    }
     for (int d = 0; d < 2; d++) {
       HDG_DISPATCH(k_cg_cell<KK, 1><<<cell_grid(), bs(), 0, stream>>>(g, cgt, dt, cg_Mloc, dt.Vuinv, nullptr, nullptr, nullptr, nullptr,
                                                                        nullptr, nullptr, const_cast<double*>(vel_in), d, cg_y));
@@ -3222,12 +3246,14 @@ struct Engine {
   // vorticity of a broken velocity in CG_{k+1} (callbacks.py:43-69); result in cg_x (ncg values)
   void vorticity(const double* vel_in) {
     cg_setup();
+    if (general) { csr(gcgd.Vort, vel_in, 1.0, 0.0, cg_b); cg_solve(); return; }
     HDG_DISPATCH(k_cg_cell<KK, 3><<<cell_grid(), bs(), 0, stream>>>(g, cgt, dt, cg_Mloc, dt.Vuinv, cg_Wx[0], cg_Wy[0], cg_Wx[1], cg_Wy[1],
                                                                      cg_Eb, nullptr, const_cast<double*>(vel_in), 0, cg_y));
     HDG_DISPATCH(k_cg_gather<KK><<<corner_grid_all(), bs(), 0, stream>>>(g_all, cgt, cg_y, cg_b));
     cg_solve();
   }
   void cg_coordinates(double* xy) const {  // physical position of every continuous dof
+    if (general) { std::memcpy(xy, gcg->xy.data(), sizeof(double) * gcg->xy.size()); return; }
     const int p = cgt.p;
     std::vector<real> gl = cfg.equispaced_nodes ? std::vector<real>() : gllPoints(p);
     if (cfg.equispaced_nodes) for (int q = 0; q <= p; q++) gl.push_back((real)q / p);
@@ -3266,6 +3292,7 @@ struct Engine {
   }
   // out = M^-1 T(.; q, u) for a continuous velocity u given as a broken modal vector
   void tracer_adv(const double* q, const double* u, double* out) {
+    if (general) { HDG_DISPATCH(k_g_tracer<KK><<<(gm->nc + 63) / 64, 64, 0, stream>>>(ggeo, q, u, out)); return; }
     halo_P(q);
     HDG_DISPATCH(k_tracer_adv<KK><<<cell_grid(), bs(), 0, stream>>>(g, dt, q, u, out));
   }
@@ -3841,7 +3868,8 @@ int hdg_cg_to_broken(hdg_handle* h, const double* cg_values, double* broken) {
   if (hipMemcpyAsync(E.cg_b, cg_values, sizeof(double) * E.cgt.ncg, hipMemcpyHostToDevice, E.stream) != hipSuccess)
     throw hdg::HipError{"hipMemcpyAsync failed"};
   const int K = E.K;
-  HDG_DISPATCH(hdg::k_cg_to_broken<KK><<<E.cell_grid(), E.bs(), 0, E.stream>>>(E.g, E.cgt, E.cg_b, E.hQ_dev));
+  if (E.general) E.csr(E.gcgd.R, E.cg_b, 1.0, 0.0, E.hQ_dev);
+  else { HDG_DISPATCH(hdg::k_cg_to_broken<KK><<<E.cell_grid(), E.bs(), 0, E.stream>>>(E.g, E.cgt, E.cg_b, E.hQ_dev)); }
   if (hipMemcpyAsync(broken, E.hQ_dev, sizeof(double) * E.NQb / 2, hipMemcpyDeviceToHost, E.stream) != hipSuccess)
     throw hdg::HipError{"hipMemcpyAsync failed"};
   HDG_API_END(h)

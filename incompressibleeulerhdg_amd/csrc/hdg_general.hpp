@@ -67,6 +67,13 @@ struct Csr {
   std::vector<int> rowptr, col;
   std::vector<double> val;
 };
+inline std::vector<double> csr_diag_of(const Csr& A) {
+  std::vector<double> d((size_t)A.nrows, 0.0);
+  for (int r = 0; r < A.nrows; r++)
+    for (int q = A.rowptr[(size_t)r]; q < A.rowptr[(size_t)r + 1]; q++)
+      if (A.col[(size_t)q] == r) d[(size_t)r] += A.val[(size_t)q];
+  return d;
+}
 struct CsrBuilder {
   int nrows, ncols;
   std::vector<std::vector<std::pair<int, double>>> rows;
@@ -606,6 +613,123 @@ inline void assemble_general(const GeneralTables& T, const GMesh& M, GeneralOps&
     }
     O.Cq = Cq.build(); O.Cqi = Cqi.build(); O.Cp = Cp.build(); O.Cpi = Cpi.build(); O.Cl = Cl.build(); O.Cli = Cli.build();
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// Continuous space CG_{k+1} on a general triangulation (common.py:110-129 velocity projection for the tracer,
+// callbacks.py:43-69 vorticity).  Dofs: vertices, then (p - 1) nodes per edge along the GLOBAL edge direction, then the interior
+// nodes cell by cell; the node of lattice index (a, b) of a cell (triangleNodes order: for b, for a) is classified like in the
+// structured engine (Engine::cg_setup) and cross-checked against the node coordinates.
+//   M      consistent mass matrix  R^T M_K R,  M_K = C_K^T C_K with C_K = sqrt(detJ) V^-1 (nodal -> orthonormal modal)
+//   Bp[d]  right-hand side of the L2 projection of velocity component d:  R^T C_K^T (modal coefficients)
+//   Ep[d]  the projected component back as a broken modal vector:  C_K R (written into the rows of component d)
+//   Vort   right-hand side of the vorticity:  -(d_x tau, Q_y) + (d_y tau, Q_x) + <tau, n_x Q_y - n_y Q_x>_{boundary}
+// ------------------------------------------------------------------------------------------
+struct GeneralCG {
+  int ncg = 0, p = 0;
+  std::vector<int> cg_of_dg;  // nc * nu
+  dvec xy, diag;              // dof coordinates (ncg x 2), diagonal of M
+  Csr M, Bp[2], Ep[2], Vort, R;  // R: continuous dofs -> broken nodal scalar field (nc * nu)
+};
+
+inline void assemble_cg(const GeneralTables& T, const GMesh& M, const GeneralOps& O, GeneralCG& C) {
+  const int nu = T.nu, n2 = T.n2, p = T.k + 1, nc = M.nc;
+  const int nint = (p - 1) * (p - 2) / 2;
+  C.p = p;
+  C.ncg = M.nv + M.ne * (p - 1) + nc * nint;
+  C.cg_of_dg.assign((size_t)nc * nu, -1);
+  C.xy.assign((size_t)C.ncg * 2, 0.0);
+  std::vector<char> seen((size_t)C.ncg, 0);
+  for (int c = 0; c < nc; c++) {
+    int n = 0, qi = 0;
+    for (int b = 0; b <= p; b++)
+      for (int a = 0; a <= p - b; a++, n++) {
+        const int cc = p - a - b;
+        int dof;
+        auto edge_dof = [&](int l, int t_loc) {
+          const int e = M.cedge[3 * (size_t)c + l];
+          const int t = M.cflip[3 * (size_t)c + l] ? p - t_loc : t_loc;
+          return M.nv + e * (p - 1) + (t - 1);
+        };
+        if (a == 0 && b == 0) dof = M.C[3 * (size_t)c + 0];
+        else if (a == p) dof = M.C[3 * (size_t)c + 1];
+        else if (b == p) dof = M.C[3 * (size_t)c + 2];
+        else if (b == 0) dof = edge_dof(0, a);       // edge v0 -> v1
+        else if (cc == 0) dof = edge_dof(1, b);      // edge v1 -> v2
+        else if (a == 0) dof = edge_dof(2, p - b);   // edge v2 -> v0
+        else dof = M.nv + M.ne * (p - 1) + c * nint + qi++;
+        C.cg_of_dg[(size_t)c * nu + n] = dof;
+        const double x = O.xq[((size_t)c * nu + n) * 2], y = O.xq[((size_t)c * nu + n) * 2 + 1];
+        if (seen[(size_t)dof]) {
+          const double tol = 1e-9 * std::sqrt(M.detJ[c]);
+          if (std::fabs(C.xy[2 * (size_t)dof] - x) > tol || std::fabs(C.xy[2 * (size_t)dof + 1] - y) > tol)
+            throw std::string("continuous space: node classification does not match the node coordinates");
+        } else {
+          seen[(size_t)dof] = 1;
+          C.xy[2 * (size_t)dof] = x; C.xy[2 * (size_t)dof + 1] = y;
+        }
+      }
+    if (n != nu || qi != nint) throw std::string("continuous space: node count mismatch");
+  }
+  const long NQ = (long)nc * n2;
+  CsrBuilder Mb(C.ncg, C.ncg), B0(C.ncg, (int)NQ), B1(C.ncg, (int)NQ), E0((int)NQ, C.ncg), E1((int)NQ, C.ncg), Vb(C.ncg, (int)NQ);
+  for (int c = 0; c < nc; c++) {
+    const double dj = M.detJ[c], sd = std::sqrt(dj);
+    const int* g = &C.cg_of_dg[(size_t)c * nu];
+    const int q0 = c * n2;
+    for (int i = 0; i < nu; i++)
+      for (int j = 0; j < nu; j++) {
+        real acc = 0;
+        for (int m = 0; m < nu; m++) acc += T.Vuinv[(size_t)m * nu + i] * T.Vuinv[(size_t)m * nu + j];
+        Mb.add(g[i], g[j], dj * (double)acc);
+      }
+    for (int m = 0; m < nu; m++)
+      for (int i = 0; i < nu; i++) {
+        const double cv = sd * (double)T.Vuinv[(size_t)m * nu + i];
+        B0.add(g[i], q0 + m, cv); B1.add(g[i], q0 + nu + m, cv);
+        E0.add(q0 + m, g[i], cv); E1.add(q0 + nu + m, g[i], cv);
+      }
+    // vorticity: modal test functions psi_a first, then tau_i = sum_a C[a][i] psi_a
+    std::vector<real> Vm((size_t)nu * n2, 0);  // row a: coefficients of (Q_x modes | Q_y modes)
+    const double* Ji = &M.Jinv[4 * (size_t)c];
+    for (int a = 0; a < nu; a++)
+      for (int m = 0; m < nu; m++) {
+        real gx = 0, gy = 0;  // int d_x psi_a psi_m,  int d_y psi_a psi_m
+        for (int rho = 0; rho < 2; rho++) {
+          gx += (real)Ji[rho * 2 + 0] * T.Gref[rho][(size_t)m * nu + a];  // Gref[rho][u][v] = int Dub_u d_rho Dub_v
+          gy += (real)Ji[rho * 2 + 1] * T.Gref[rho][(size_t)m * nu + a];
+        }
+        Vm[(size_t)a * n2 + nu + m] -= gx;  // -(d_x tau) Q_y
+        Vm[(size_t)a * n2 + m] += gy;       // +(d_y tau) Q_x
+      }
+    for (int l = 0; l < 3; l++) {
+      const int e = M.cedge[3 * (size_t)c + l];
+      if (M.ecell[2 * (size_t)e + 1] >= 0) continue;  // boundary edges only
+      const int tabi = l * 2 + M.cflip[3 * (size_t)c + l];
+      const real sg = (real)M.csig[3 * (size_t)c + l], nx = sg * (real)M.enx[e], ny = sg * (real)M.eny[e];
+      const real sc = (real)M.elen[e] / (real)dj;  // weights sum to 1 along the edge; both basis functions carry 1 / sqrt(detJ)
+      for (int q = 0; q < T.nqe; q++)
+        for (int a = 0; a < nu; a++)
+          for (int m = 0; m < nu; m++) {
+            const real v = sc * (real)T.ew[(size_t)q] * (real)T.ePhi[((size_t)tabi * T.nqe + q) * nu + a] * (real)T.ePhi[((size_t)tabi * T.nqe + q) * nu + m];
+            Vm[(size_t)a * n2 + nu + m] += nx * v;  // tau n_x Q_y
+            Vm[(size_t)a * n2 + m] -= ny * v;       // -tau n_y Q_x
+          }
+    }
+    for (int i = 0; i < nu; i++)
+      for (int cc = 0; cc < n2; cc++) {
+        real acc = 0;
+        for (int a = 0; a < nu; a++) acc += (real)sd * T.Vuinv[(size_t)a * nu + i] * Vm[(size_t)a * n2 + cc];
+        Vb.add(g[i], q0 + cc, (double)acc);
+      }
+  }
+  C.M = Mb.build(); C.Bp[0] = B0.build(); C.Bp[1] = B1.build(); C.Ep[0] = E0.build(); C.Ep[1] = E1.build(); C.Vort = Vb.build();
+  C.diag = csr_diag_of(C.M);
+  C.R.nrows = nc * nu; C.R.ncols = C.ncg;
+  C.R.rowptr.resize((size_t)nc * nu + 1);
+  for (int i = 0; i <= nc * nu; i++) C.R.rowptr[(size_t)i] = i;
+  C.R.col = C.cg_of_dg;
+  C.R.val.assign((size_t)nc * nu, 1.0);
 }
 
 // element block-Jacobi of the tentative-velocity operator,  (I + gamma sum_e alpha / len_e N_e^T N_e)^-1  per cell

@@ -127,6 +127,65 @@ __global__ __launch_bounds__(64) void k_g_adv(GGeo G, const double* __restrict__
   }
 }
 
+// Passive tracer transport on a general triangulation (common.py:110-129; k_tracer_adv of the structured engine):
+//   out_i = int_K q (grad chi_i . u + chi_i div u) - sum_{interior e} int_e chi_i (un_K q_K - un_K' q_K'),
+//   un_K = (u.n_K + |u.n_K|)/2, un_K' = (|u.n_K| - u.n_K)/2; u is continuous, so it is taken from this cell.
+// Tracer modes = the first NP velocity modes (hierarchical basis, same scaling): the advection tabulations serve both.
+template <int K>
+__global__ __launch_bounds__(64) void k_g_tracer(GGeo G, const double* __restrict__ qin, const double* __restrict__ u,
+                                                 double* __restrict__ out) {
+  constexpr int NU = Dim<K>::NU, NP = Dim<K>::NP, N2 = 2 * NU;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= G.nc) return;
+  double qc[NP], uc[N2], F[NP];
+#pragma unroll
+  for (int r = 0; r < NP; r++) { qc[r] = qin[(long)c * NP + r]; F[r] = 0.0; }
+#pragma unroll
+  for (int n = 0; n < N2; n++) uc[n] = u[(long)c * N2 + n];
+  const double s = G.inv_sdet[c], dj = G.detJ[c];
+  const double j00 = G.Jinv[4 * (long)c + 0] * s, j01 = G.Jinv[4 * (long)c + 1] * s, j10 = G.Jinv[4 * (long)c + 2] * s,
+               j11 = G.Jinv[4 * (long)c + 3] * s;
+  for (int q = 0; q < G.nqc; q++) {
+    double qq = 0, ux = 0, uy = 0, dv = 0;
+    for (int m = 0; m < NU; m++) {
+      const double ph = G.cPhi[q * NU + m] * s, gxi = G.cGxi[q * NU + m], get = G.cGeta[q * NU + m];
+      ux = fma(ph, uc[m], ux);
+      uy = fma(ph, uc[NU + m], uy);
+      dv = fma(j00 * gxi + j10 * get, uc[m], fma(j01 * gxi + j11 * get, uc[NU + m], dv));
+      if (m < NP) qq = fma(ph, qc[m], qq);
+    }
+    const double w = G.cw[q] * dj * qq;
+    for (int r = 0; r < NP; r++) {
+      const double gxi = G.cGxi[q * NU + r], get = G.cGeta[q * NU + r];
+      F[r] = fma(w, fma(j00 * gxi + j10 * get, ux, fma(j01 * gxi + j11 * get, uy, G.cPhi[q * NU + r] * s * dv)), F[r]);
+    }
+  }
+  for (int l = 0; l < 3; l++) {
+    const int cn = G.cnbr[3 * (long)c + l];
+    if (cn < 0) continue;
+    const double* __restrict__ Po = G.ePhi + (long)G.ctab[3 * (long)c + l] * G.nqe * NU;
+    const double* __restrict__ Pn = G.ePhi + (long)G.ntab[3 * (long)c + l] * G.nqe * NU;
+    const double sn = G.inv_sdet[cn], sg = G.csig[3 * (long)c + l];
+    const double nxo = sg * G.cenx[3 * (long)c + l], nyo = sg * G.ceny[3 * (long)c + l], len = G.celen[3 * (long)c + l];
+    double qn[NP];
+#pragma unroll
+    for (int r = 0; r < NP; r++) qn[r] = qin[(long)cn * NP + r];
+    for (int q = 0; q < G.nqe; q++) {
+      double un = 0, qk = 0, qm = 0;
+      for (int m = 0; m < NU; m++) {
+        const double po = Po[q * NU + m] * s;
+        un = fma(po, fma(nxo, uc[m], nyo * uc[NU + m]), un);
+        if (m < NP) { qk = fma(po, qc[m], qk); qm = fma(Pn[q * NU + m] * sn, qn[m], qm); }
+      }
+      const double a = fabs(un);
+      const double flux = G.ew[q] * len * (0.5 * (un + a) * qk - 0.5 * (a - un) * qm);
+      for (int r = 0; r < NP; r++) F[r] = fma(-Po[q * NU + r] * s, flux, F[r]);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < NP; r++) out[(long)c * NP + r] = F[r];
+}
+
 // v = -b + (Q.grad) Q at one point from tabulated values / reference gradients of one cell
 template <int NU>
 __device__ __forceinline__ void g_point_v(const double* __restrict__ Ph, const double* __restrict__ Gxi, const double* __restrict__ Geta,

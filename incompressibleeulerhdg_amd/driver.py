@@ -5,7 +5,7 @@
 ``--problem taylorgreen`` (unit square), ``--problem shear`` (doubly periodic square, driver.py:182-183) and
 ``--problem kelvinhelmholtz`` (UnitDiskMesh(refinement), driver.py:184-185: the general-mesh path, projection and monolithic)
 are built; the ``conforming`` / ``dg`` discretisations raise.  ``--animation`` (evolution.pvd with
-the CG vorticity, callbacks.py:30-85) and ``--tracer_advection`` (driver.py:340-344) work on the two square meshes.  The final fields are written to ``solution.pvd``
+the CG vorticity, callbacks.py:30-85) and ``--tracer_advection`` (driver.py:340-344) work on every mesh.  The final fields are written to ``solution.pvd``
 (``--output``) like the reference does (driver.py:356-385).
 """
 import argparse

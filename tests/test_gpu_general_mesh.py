@@ -278,3 +278,83 @@ def test_general_mesh_monolithic_solves(hip_lib, kind, k, stepper):
     assert _rel(Q.dat.data, oQ) < TOL and _rel(p.dat.data, op) < TOL
     sums, cnt = ts._engine.iteration_stats()
     assert np.all(sums[cnt > 0] / cnt[cnt > 0] < 200)
+
+
+@pytest.mark.parametrize("kind,k", [("disk1", 1), ("irregular", 2), ("disk2", 2), ("square4", 3), ("irregular", 4)])
+def test_general_mesh_continuous_space_and_tracer_operator(hip_lib, kind, k):
+    """CG_{k+1} on a general triangulation (common.py:110-129, callbacks.py:43-69): dof set, L2 projection of a broken velocity,
+    vorticity and the tracer transport operator against the oracle's restatement (oracle/tracer_oracle.py on the TriMesh)."""
+    from oracle.hdg_oracle import HDGDiscretisation
+    from oracle.tracer_oracle import TracerOracle
+
+    pm, om = _mesh(kind)
+    d = HDGDiscretisation(0, k, mesh=om)
+    tr = TracerOracle(d)
+    e = _engine(pm, k)
+    assert e.cg_size() == tr.ncg
+    key = lambda X: {tuple(np.round(x * 1e6).astype(np.int64)) for x in X}
+    assert key(e.cg_coordinates()) == key(tr.cg_coords) and len(key(e.cg_coordinates())) == tr.ncg
+    rng = np.random.default_rng(50 + k)
+    u = rng.standard_normal(e.shape_Q)
+    P = e.cg_project_nodal(u)
+    assert _rel(P, tr.cg_project(u)) < 1e-10
+    assert _rel(e.cg_project_nodal(P), P) < 1e-10
+    cont = d.interpolate_velocity(lambda x, y: (x ** (k + 1) - y, x * y ** k + 1.0))
+    assert _rel(e.cg_project_nodal(cont), cont) < 1e-10
+    Q = rng.standard_normal(e.shape_Q)
+    w, xy = tr.vorticity(Q)
+    wd = e.vorticity(Q)
+    order = lambda X: np.lexsort((np.round(X[:, 1] * 1e6), np.round(X[:, 0] * 1e6)))
+    assert _rel(wd[order(e.cg_coordinates())], w[order(xy)]) < 1e-10
+    assert _rel(e.cg_to_broken(wd), tr.R @ w) < 1e-10
+    # rigid rotation (-y, x): vorticity 2 everywhere, also on the polygonal boundary
+    rot = d.interpolate_velocity(lambda x, y: (-y, x))
+    assert np.max(np.abs(e.vorticity(rot) - 2.0)) < 1e-9
+    q = rng.standard_normal(e.shape_p)
+    assert _rel(e.apply_tracer_advection(q, u, project=True), tr.tracer_tendency(q, u)) < 1e-10
+    uc = tr.cg_project(u)
+    assert _rel(e.apply_tracer_advection(q, uc, project=False), tr._lu_mp.solve(tr.tracer_form(q, uc))) < 1e-10
+
+
+@pytest.mark.parametrize("kind,k,tableau", [("disk1", 1, "imex_ssp2_332"), ("irregular", 2, "imex_ars3_443"), ("disk1", 2, "implicit")])
+def test_general_mesh_steps_with_tracer(hip_lib, kind, k, tableau):
+    """Whole steps with a passive tracer on a general triangulation (hdg_imex.py:415-448,560,622-623,638-639;
+    hdg_implicit.py:93-96,192-193) against the oracle."""
+    from incompressibleeulerhdg_amd import timesteppers as tsm
+    from oracle import hdg_oracle as orc
+    from oracle.tracer_oracle import TracerOracle, imex_with_tracer, implicit_with_tracer
+
+    pm, om = _mesh(kind)
+    dt = 0.02
+    Q0, p0, f = _smooth(41 + k)
+    q0 = lambda x, y: np.sin(1.5 * x + 0.3) * np.cos(1.2 * y) + 0.2 * x
+    d = orc.HDGDiscretisation(0, k, mesh=om)
+    tr = TracerOracle(d)
+    fo = lambda t: d.interpolate_velocity(f(t))
+    args = (d.interpolate_velocity(Q0), d.interpolate_pressure(p0), d.interpolate_pressure(q0), fo, 2 * dt)
+    if tableau == "implicit":
+        oQ, op, oq = implicit_with_tracer(d, tr, dt, *args)
+        ts = tsm.IncompressibleEulerHDGImplicit(pm, k, dt, use_projection_method=True)
+    else:
+        oQ, op, oq = imex_with_tracer(orc.OracleHDGIMEX(d, dt, tableau), tr, *args)
+        cls = {"imex_ssp2_332": tsm.IncompressibleEulerHDGIMEXSSP2_332, "imex_ars3_443": tsm.IncompressibleEulerHDGIMEXARS3_443}[tableau]
+        ts = cls(pm, k, dt, use_projection_method=True)
+    Q, p = ts.solve(Q0, p0, q0, f, 2 * dt)
+    assert _rel(Q.dat.data, oQ) < TOL and _rel(p.dat.data, op) < TOL and _rel(ts.q_tracer.dat.data, oq) < TOL
+    assert _rel(oq, d.interpolate_pressure(q0)) > 1e-3  # the tracer moved
+
+
+def test_driver_kelvin_helmholtz_with_tracer_and_animation(hip_lib, tmp_path, capsys, monkeypatch):
+    """The reference driver's Kelvin-Helmholtz run with its DEFAULT (monolithic) solve, --animation (CG vorticity) and
+    --tracer_advection on the disk (driver.py:97-102,165-176,184-187,336-344)."""
+    from incompressibleeulerhdg_amd import driver
+
+    monkeypatch.chdir(tmp_path)
+    driver.main(["--problem", "kelvinhelmholtz", "--refinement", "1", "--degree", "1", "--dt", "0.02", "--tfinal", "0.04",
+                 "--tracer_advection", "--animation", "--output", ""])
+    out = capsys.readouterr().out
+    assert "use projection method = False" in out and "advect tracer = True" in out
+    assert (tmp_path / "evolution.pvd").read_text().count("<DataSet") == 3
+    vtu = (tmp_path / "evolution_2.vtu").read_text()
+    for name in ('Name="Q"', 'Name="p"', 'Name="vorticity"', 'Name="tracer"'):
+        assert name in vtu, name
