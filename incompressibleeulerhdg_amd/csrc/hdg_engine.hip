@@ -2697,6 +2697,13 @@ struct Engine {
     HIPCHECK(hipMemsetAsync(d_cgs, 0, sizeof(double) * 8, stream));
     double norm0 = -1.0;
     int its = 0;
+    // Attainable accuracy.  A solve whose right-hand side is tiny against the solution it corrects (second Richardson pass,
+    // k = 4 on 2048^2: |z0| = 2e-4) cannot reduce its residual by 1e-12: the recurrences stall a few units above the target at
+    // the rounding level of T x and p.Ap eventually turns non-positive.  A Krylov solver of the reference would sit there
+    // until its iteration limit and carry on; here a residual within three decades of the target that has not halved for three
+    // iterations (or a breakdown at that level) ends the solve as converged to the attainable accuracy.
+    double best = 1e300, last = 1e300;
+    int since_best = 0;
     while (true) {
       bool have_dots = false;
       if (!trace_precond(cg_r, cg_z, cg_Ap, &have_dots)) trace_apply(cg_z, nullptr, 0.0, 1.0, cg_Ap);  // w = T z
@@ -2712,7 +2719,13 @@ struct Engine {
       fl.set(x, 0);
       // snapshot of iteration `its` (cg_z is intact: the next preconditioner application has not been queued)
       HIPCHECK(hipEventSynchronize(cg_ev));
-      if (h_cgs[6] == 1.0) throw NotConverged{"trace CG: breakdown (p.Ap <= 0)"};
+      if (h_cgs[6] == 1.0) {  // alpha was set to 0: the update just queued leaves x alone
+        if (its > 0 && last <= 1e3 * rtol * norm0) {
+          if (debug_cg()) fprintf(stderr, "[cg] it %d: p.Ap <= 0 at |z|/|z0| %.3e: attainable accuracy, accepted\n", its, last / norm0);
+          return its;
+        }
+        throw NotConverged{"trace CG: breakdown (p.Ap <= 0)"};
+      }
       double zz = h_cgs[4];
       if (h_cgs[6] == 2.0) {  // z almost parallel to the null vector: measure the projected norm explicitly
         axpby(NLv, -h_cgs[3], tr_one, 1.0, cg_z);
@@ -2725,6 +2738,12 @@ struct Engine {
       if (its == 0) { norm0 = nrm; if (norm0 == 0.0) return 0; }
       if (debug_cg()) fprintf(stderr, "[cg] it %d |z|/|z0| %.3e  c %.3e rz %.3e\n", its, nrm / norm0, h_cgs[3], h_cgs[0]);
       if (its > 0 && nrm <= rtol * norm0) return its;
+      last = nrm;
+      if (nrm < 0.5 * best) { best = nrm; since_best = 0; } else since_best++;
+      if (its > 0 && since_best >= 3 && nrm <= 1e3 * rtol * norm0) {
+        if (debug_cg()) fprintf(stderr, "[cg] it %d: stalled at |z|/|z0| %.3e: attainable accuracy, accepted\n", its, nrm / norm0);
+        return its;
+      }
       if (its >= maxit) {
         if (strict) throw NotConverged{"trace CG reached max iterations"};
         return its;

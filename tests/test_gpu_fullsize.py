@@ -48,11 +48,13 @@ def test_operator_properties_at_baseline_size(hip_lib, k, nx):
     assert np.max(np.abs(e.get_field(1, p=False, lam=False)[0] - x)) < 1e-12 * np.max(np.abs(x))
 
 
-@pytest.mark.parametrize("k,nx,nsteps", [(1, 256, 3), (2, 1024, 2), (3, 512, 1), (4, 256, 1), (4, 2048, 1)])
+@pytest.mark.parametrize("k,nx,nsteps", [(1, 256, 3), (2, 1024, 2), (3, 512, 1), (4, 256, 1), (4, 2048, 3)])
 def test_timestep_properties_at_baseline_size(hip_lib, k, nx, nsteps):
     """C2 (k=1, 256^2), C3 (k=2, 1024^2) and C5 (k=4, 2048^2: 541 M unknowns on ONE MI355X) of BASELINE.json, plus the
     matrix-core kernels at k = 3, 4 on meshes with many tiles: the error against the exact vortex catches a wrong
-    stencil / neighbour index at sizes the oracle cannot reach."""
+    stencil / neighbour index at sizes the oracle cannot reach.  C5 runs three steps: in the third the second Richardson pass
+    has a right-hand side so small against the pressure it corrects that the CG stalls at the rounding level a few units above
+    rtol * |z0| (the attainable-accuracy exit of Engine::trace_cg_sr; before it this step ended in "breakdown (p.Ap <= 0)")."""
     from incompressibleeulerhdg_amd import _lib
 
     ts, mp = _stepper(k, nx)
