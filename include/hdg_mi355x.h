@@ -95,9 +95,11 @@ int hdg_create(const hdg_config* cfg, hdg_handle** out);
  * mesh of the Kelvin-Helmholtz set-up (src/model_problems.py:108-131), or any conforming triangulation: coords (n_vertices, 2),
  * cells (n_cells, 3) vertex numbers.  cfg.nx / ny / periodic / length are ignored.  The handle serves the same entry points
  * (state, per-solve calls, hdg_step / hdg_run_separable, norms, node coordinates); per-element geometry replaces the two
- * shared element shapes: assembled solution-independent operators + hand-written advection / reconstruction kernels, GMRES
- * with element block-Jacobi for the tentative velocity (hdg_imex.py:223-255), condensation + CG with the edge block-Jacobi
- * (ASMStarPC of hdg_imex.py:143-152, no coarse space) for the pressure.  Single rank, projection method, no tracer.
+ * shared element shapes: assembled solution-independent operators + hand-written advection / reconstruction / tracer kernels,
+ * GMRES with the hybrid two-level preconditioner for the tentative velocity (hdg_imex.py:223-255), condensation + CG with
+ * Chebyshev / edge block-Jacobi smoothing (ASMStarPC of hdg_imex.py:143-152) and a P1 coarse space solved by a
+ * smoothed-aggregation V-cycle (GTMG + GAMG of hdg_imex.py:139-167) for the pressure; projection and monolithic solves,
+ * tracer and vorticity (hdg_tracer_*, hdg_vorticity, hdg_cg_*) as on the structured meshes.  Single rank.
  * Numbering at the boundary: cells as given; local edge l joins vertices l and (l+1)%3 of its cell; edges in order of first
  * appearance while walking the cells, directed from the lower to the higher vertex number; velocity / pressure nodes: the
  * lattice of the structured path on x = v0 + (v1 - v0) xi + (v2 - v0) eta; trace nodes along the edge direction.

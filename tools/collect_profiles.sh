@@ -34,7 +34,8 @@ tail -25 $R/gpurun_out/summary_$TAG.log
 rm -rf $O
 # the bench lines of the same build, with roofline.traffic from the file just written (same source hash)
 cp $S/pmc_traffic.json $R/profiles/pmc_traffic.json
-python3 bench.py > $S/${TAG}_bench_c3.json 2> $R/gpurun_out/bench_c3_$TAG.err
-python3 bench.py --degree 3 --nx 512 --no-cpu-baseline > $S/${TAG}_bench_k3.json 2> $R/gpurun_out/bench_k3_$TAG.err
-python3 bench.py --degree 4 --nx 512 --no-cpu-baseline > $S/${TAG}_bench_k4.json 2> $R/gpurun_out/bench_k4_$TAG.err
+# (the driver's window: 20 timed steps after 5 warm-up steps -- the first solves of a run still learn their check schedule)
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > $S/${TAG}_bench_c3.json 2> $R/gpurun_out/bench_c3_$TAG.err
+python3 bench.py --degree 3 --nx 512 --steps 20 --warmup 5 --no-cpu-baseline > $S/${TAG}_bench_k3.json 2> $R/gpurun_out/bench_k3_$TAG.err
+python3 bench.py --degree 4 --nx 512 --steps 20 --warmup 5 --no-cpu-baseline > $S/${TAG}_bench_k4.json 2> $R/gpurun_out/bench_k4_$TAG.err
 ls $S
