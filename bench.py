@@ -106,8 +106,8 @@ def roofline_block(eng, args, nx, k, world, ktimers=None, timed_where="the timed
       Chebyshev phase (default):  k_adv_apply<K, true> / k_adv_mfma<K, true>: residual form t = b - (I - gamma F(Q*)) x
                                   (reads x, Q*, b, writes t: 4 vectors of 8 N_Q bytes, SURVEY.md section 8d);
                                   k <= 2: k_edge_lift<K, false, 2, true> with the fused Chebyshev step (reads t, x_n, x_{n-1},
-                                  writes x_{n+1}: 4 vectors);  k >= 3: k_edge_lift_mfma<K> (reads t, writes z: 2 vectors) -- the
-                                  Chebyshev step is a separate vector kernel there (k_cheb_update, NOT inside the bracket);
+                                  writes x_{n+1}: 4 vectors);  k >= 3: k_edge_lift_mfma<K, true>, the matrix-core lift with the same
+                                  fused step (4 vectors; HDG_MFMA_CHEB_UNFUSED: plain lift + separate k_cheb_update);
       GMRES phase:                k_adv_apply<K, false> / k_adv_mfma<K, false> (reads x, Q*, writes y: 3 vectors) and the plain
                                   lift (2 vectors).
     k <= 2: bound HBM.  k >= 3: bound FP64 MFMA; `achieved` counts the ALGORITHMIC flops (unpadded contraction shapes),
@@ -138,7 +138,7 @@ def roofline_block(eng, args, nx, k, world, ktimers=None, timed_where="the timed
                     kn = cfg["kernels"]
                     fm = "true" if cheb else "false"
                     for key, names in (("adv", (f"k_adv_apply<{k}, {fm}>", f"k_adv_mfma<{k}, {fm}>")),
-                                       ("lift", (f"k_edge_lift<{k}, false, 2, {fm}>", f"k_edge_lift_mfma<{k}>"))):
+                                       ("lift", (f"k_edge_lift<{k}, false, 2, {fm}>", f"k_edge_lift_mfma<{k}, {fm}>"))):
                         for nm in names:
                             if nm in kn and (k <= 2) == ("mfma" not in nm):
                                 pmc[key] = kn[nm]["hbm_bytes"]
@@ -186,8 +186,12 @@ def roofline_block(eng, args, nx, k, world, ktimers=None, timed_where="the timed
     in_place = lambda lab, alone: (ktimers[lab][1] / ktimers[lab][0] * 1e3, ktimers[lab][0]) if ktimers and ktimers.get(lab, (0, 0))[0] else (alone, 0)
     (ms_lift, n_lift), (ms_adv, n_adv) = in_place("kernel_lift", ms_lift_alone), in_place("kernel_advection", ms_adv_alone)
     tf = lambda fl, ms: fl / (ms * 1e-3) / 1e12
-    others[f"k_edge_lift_mfma<{k}>"] = dict(ms=ms_lift, TFLOPs=tf(lift_alg, ms_lift), mfma_util=tf(lift_issued, ms_lift) / FP64_MATRIX_PEAK_TF,
-                                             GBs=gbs(8.0 * 2 * NQ, ms_lift), algorithmic_bytes=8.0 * 2 * NQ, traffic=pmc.get("lift"),
+    # in place: the form the solver iterates with (Chebyshev phase: fused step, 4 vectors); stand-alone loop: the plain lift
+    fused = cheb and n_lift > 0 and not os.environ.get("HDG_MFMA_CHEB_UNFUSED")
+    nv_lift = 4 if fused else 2
+    lift_label = f"k_edge_lift_mfma<{k}, {'true' if fused else 'false'}>" + (" (lift + fused Chebyshev step)" if fused else "")
+    others[lift_label] = dict(ms=ms_lift, TFLOPs=tf(lift_alg, ms_lift), mfma_util=tf(lift_issued, ms_lift) / FP64_MATRIX_PEAK_TF,
+                                             GBs=gbs(8.0 * nv_lift * NQ, ms_lift), algorithmic_bytes=8.0 * nv_lift * NQ, traffic=pmc.get("lift"),
                                              mfma_busy_pmc=pmc_mfma.get("lift"), launches_timed=n_lift, ms_stand_alone=ms_lift_alone)
     nv_adv = 4 if cheb else 3  # residual form reads b as well
     return dict(bound="mfma", kernel=f"k_adv_mfma<{k}, {'true' if cheb else 'false'}>" + (" (residual form)" if cheb else ""),

@@ -1170,8 +1170,18 @@ struct Engine {
   }
   // HDG_MFMA_K2 (experiment): the matrix-core kernels at k = 2 as well (north_star: "MFMA at k >= 2")
   static int mfma_min_degree() { static const int d = std::getenv("HDG_MFMA_K2") ? 2 : 3; return d; }
-  void lift_mfma(const Geo& gx, const double* t0, const double* t1, const double* in, double* out) {
+  void lift_mfma(const Geo& gx, const double* t0, const double* t1, const double* in, double* out, double* chd_ = nullptr,
+                 const double* chx_ = nullptr, double c1 = 0.0, double c2 = 0.0) {
     const dim3 grid(8 * gx.rows_xcd * 2);
+    if (chd_) {  // with the fused Chebyshev step
+      switch (cfg.degree) {
+        case 2: k_edge_lift_mfma<2, true><<<grid, 64 * HDG_LIFT_MFMA_WAVES, 0, stream>>>(gx, t0, t1, in, out, chd_, chx_, c1, c2); break;
+        case 3: k_edge_lift_mfma<3, true><<<grid, 64 * HDG_LIFT_MFMA_WAVES, 0, stream>>>(gx, t0, t1, in, out, chd_, chx_, c1, c2); break;
+        case 4: k_edge_lift_mfma<4, true><<<grid, 64 * HDG_LIFT_MFMA_WAVES, 0, stream>>>(gx, t0, t1, in, out, chd_, chx_, c1, c2); break;
+        default: throw std::string("MFMA lift: degree out of range");
+      }
+      return;
+    }
     switch (cfg.degree) {
       case 2: k_edge_lift_mfma<2><<<grid, 64 * HDG_LIFT_MFMA_WAVES, 0, stream>>>(gx, t0, t1, in, out); break;
       case 3: k_edge_lift_mfma<3><<<grid, 64 * HDG_LIFT_MFMA_WAVES, 0, stream>>>(gx, t0, t1, in, out); break;
@@ -1228,10 +1238,10 @@ struct Engine {
     if (chd_) { pw.push_back(chx_); if (c1 != 0.0) pw.push_back(chd_); }
     int ext = 0;
     stencil_launch(in, FQ, GH, false, pw, [&](const Geo& gx) {
-      if (use_mfma_lift() && out && !chd_ && !ss) {
-        // GMRES path at k >= 3: no Chebyshev epilogue -> matrix-core kernel with the packed G tables of this stage
+      if (use_mfma_lift() && !ss && (out || chd_)) {
+        // k >= 3: matrix-core kernel with the packed G tables of this stage (GMRES path: plain; Chebyshev path: fused step)
         for (size_t q = 0; q < hybg0.size(); q++)
-          if (hybg0[q] == D0) { lift_mfma(gx, liftm_hyb0[q], liftm_hyb1[q], in, out); return; }
+          if (hybg0[q] == D0) { lift_mfma(gx, liftm_hyb0[q], liftm_hyb1[q], in, out, chd_, chx_, c1, c2); return; }
       }
       if (chd_) { HDG_DISPATCH(k_edge_lift<KK, false, 2, true><<<cell_grid_of(gx), bs(), 0, stream>>>(gx, dt, in, out, nullptr, D0, D1, chd_, chx_, c1, c2, ss)); }
       else { HDG_DISPATCH(k_edge_lift<KK, false, 2, false><<<cell_grid_of(gx), bs(), 0, stream>>>(gx, dt, in, out, nullptr, D0, D1, chd_, chx_, c1, c2, ss)); }
@@ -1805,6 +1815,10 @@ struct Engine {
     HIPCHECK(hipStreamSynchronize(stream));
     dinv_gamma[idx] = gamma;
   }
+  static bool mfma_cheb_unfused() {
+    static const bool v = std::getenv("HDG_MFMA_CHEB_UNFUSED") != nullptr;
+    return v;
+  }
   // z = M r  (tentative-velocity preconditioner)
   void tent_precond(int didx, const double* r, double* z) {
     if (general) {
@@ -1843,11 +1857,14 @@ struct Engine {
     } else if (cfg.tent_precond == 1) {
       bdm_T(r, wQ3);
       bdm_plus_bj(wQ3, zout, r, dinv0[didx], dinv1[didx], d_, x_, c1, c2);
-    } else if (use_mfma_lift()) {
-      // k >= 3: the lift runs on the matrix cores (no fused epilogue there); the Chebyshev step is one vector kernel
+    } else if (use_mfma_lift() && mfma_cheb_unfused()) {
+      // k >= 3, round-2 form (HDG_MFMA_CHEB_UNFUSED): matrix-core lift, then the Chebyshev step as one vector kernel
       bdm_hybrid(r, wQ4, hybg0[didx], hybg1[didx]);
       if (zout) copy(zout, wQ4, NQ);
       cheb_update(d_, wQ4, x_, c1, c2);
+    } else if (use_mfma_lift()) {
+      // k >= 3: matrix-core lift with the Chebyshev step in its store epilogue (z is stored at check points only)
+      bdm_hybrid(r, zout, hybg0[didx], hybg1[didx], d_, x_, c1, c2, nullptr);
     } else {
       bdm_hybrid(r, zout, hybg0[didx], hybg1[didx], d_, x_, c1, c2, cell_norm ? cell_ss : nullptr);
     }

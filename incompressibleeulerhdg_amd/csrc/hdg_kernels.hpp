@@ -433,9 +433,15 @@ struct LiftMfma {
 // 8 mt + 4 + lk in 2, 3 -- the SAME pairs (q = 2 mt, 2 mt + 1), so the loaded own coefficients are B operands and
 // accumulator start values at once, and a tile is stored with two buffer_store_dwordx4 (Engine::scol / srow pack the
 // tables accordingly).  Before: 8-byte accesses in memory order, 56 loads + 12 stores per cell tile; now 24 + 6.
-template <int K>
+// CHEB (its own instantiation and kernel name): the Chebyshev step of the tentative-velocity iteration in the store epilogue,
+//   x_{n+1} = x_n + c1 (x_n - x_{n-1}) + c2 z   (chx = x_n, chd = x_{n-1} on entry and x_{n+1} on exit, z = this kernel's result,
+// stored only when out != nullptr: the check points of the iteration) -- what the per-thread lift does at k <= 2; before, the
+// matrix-core lift was followed by a separate vector kernel (k_cheb_update: 4 more passes over velocity vectors).
+template <int K, bool CHEB = false>
 __global__ __launch_bounds__(64 * HDG_LIFT_MFMA_WAVES) void k_edge_lift_mfma(Geo g, const double* __restrict__ tabs0, const double* __restrict__ tabs1,
-                                                         const double* __restrict__ in, double* __restrict__ out) {
+                                                         const double* __restrict__ in, double* __restrict__ out,
+                                                         double* __restrict__ chd = nullptr, const double* __restrict__ chx = nullptr,
+                                                         double c1 = 0.0, double c2 = 0.0) {
   typedef LiftMfma<K> L;
   constexpr int NU = L::NU, NE = L::NE, KQ = L::KQ, KS = L::KS, MT = L::MT, KD = L::KD;
   __shared__ double tab[L::NTILES * 64];
@@ -454,7 +460,7 @@ __global__ __launch_bounds__(64 * HDG_LIFT_MFMA_WAVES) void k_edge_lift_mfma(Geo
   const double* __restrict__ tW = tab;                     // [2][KS][64]
   const double* __restrict__ tN = tab + 2 * KS * 64;       // [3][KS][64]
   const double* __restrict__ tG = tab + 5 * KS * 64;       // [MT][KD][64]
-  const VelBuf Bin(in), Bout(out);
+  const VelBuf Bin(in), Bout(out), Bp(CHEB ? chd : out), Bx(CHEB ? chx : in);
   const int gj = g.joff + j;
   const bool has0 = s == 0 ? gj > 0 : gj < g.nyg - 1;
   const int jn0 = s == 0 ? j - 1 : j + 1;
@@ -516,12 +522,26 @@ __global__ __launch_bounds__(64 * HDG_LIFT_MFMA_WAVES) void k_edge_lift_mfma(Geo
     for (int mt = 0; mt < MT; mt++) {
       const hdg_d2 lo = xo[2 * mt], hi = (2 * mt + 1 < KQ) ? xo[(2 * mt + 1 < KQ) ? 2 * mt + 1 : 0] : zero2;
       hdg_v4d Y = {lo.x, lo.y, hi.x, hi.y};
+      const int m0 = 8 * mt + lk, m1 = m0 + 4;
+      hdg_d2 xa = zero2, xb = zero2, pa = zero2, pb = zero2;
+      if (CHEB) {  // requested before the lifting products (clamped column: in bounds)
+        xa = ld_pair_lane<NU>(Bx, g.Nc, c, m0); xb = ld_pair_lane<NU>(Bx, g.Nc, c, m1);
+        if (c1 != 0.0) { pa = ld_pair_lane<NU>(Bp, g.Nc, c, m0); pb = ld_pair_lane<NU>(Bp, g.Nc, c, m1); }
+        else { pa = xa; pb = xb; }
+      }
 #pragma unroll
       for (int kd = 0; kd < KD; kd++) Y = __builtin_amdgcn_mfma_f64_16x16x4f64(tG[(mt * KD + kd) * 64 + l], bd[kd], Y, 0, 0, 0);
       if (col) {
-        const int m0 = 8 * mt + lk, m1 = m0 + 4;
-        if (m0 < NU) st_pair_lane(Bout, g.Nc, c, m0, hdg_d2{Y[0], Y[1]});
-        if (m1 < NU) st_pair_lane(Bout, g.Nc, c, m1, hdg_d2{Y[2], Y[3]});
+        if (!CHEB || out) {
+          if (m0 < NU) st_pair_lane(Bout, g.Nc, c, m0, hdg_d2{Y[0], Y[1]});
+          if (m1 < NU) st_pair_lane(Bout, g.Nc, c, m1, hdg_d2{Y[2], Y[3]});
+        }
+        if (CHEB) {
+          const hdg_d2 na = {fma(c1, xa.x - pa.x, fma(c2, Y[0], xa.x)), fma(c1, xa.y - pa.y, fma(c2, Y[1], xa.y))};
+          const hdg_d2 nb = {fma(c1, xb.x - pb.x, fma(c2, Y[2], xb.x)), fma(c1, xb.y - pb.y, fma(c2, Y[3], xb.y))};
+          if (m0 < NU) st_pair_lane(Bp, g.Nc, c, m0, na);
+          if (m1 < NU) st_pair_lane(Bp, g.Nc, c, m1, nb);
+        }
       }
     }
   }
