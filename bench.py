@@ -335,6 +335,33 @@ def reassembly_split(eng, k, nx, cb, gpu_s_per_step):
                      "both sides of the reported GPU/CPU ratio skip it, so the ratio is kernel + solver efficiency only")
 
 
+def alt_stop_rule(build, args, dt, kappa, mp, ssp2_scales, tol="1e-15"):
+    """The timed steps once more on a fresh engine with HDG_TRACE_BACKWARD_TOL (read when an engine is built): condensed solves
+    stop when their preconditioned residual is below tol * |pressure trace| -- ten units in the last place of the field they
+    correct -- or at the reference's rtol 1e-12, whichever comes first; update solves start from zero."""
+    os.environ["HDG_TRACE_BACKWARD_TOL"] = tol
+    try:
+        ts2 = build("none")
+        e2 = ts2._engine
+        e2.set_state(ts2._V_Q.interpolate(mp.Q_stationary), ts2._V_p.interpolate(mp.p_stationary))
+        e2.reconstruct_trace()
+        e2.set_forcing_profile(mp.f_rhs().profile)
+        if args.warmup > 0:
+            e2.run_separable(ssp2_scales(args.warmup, dt, kappa))
+        e2.iteration_stats(reset=True)
+        t0 = time.perf_counter()
+        e2.run_separable(ssp2_scales(args.steps, dt, kappa, t0=args.warmup * dt))
+        el = time.perf_counter() - t0
+        sums, cnt = e2.iteration_stats()
+        its = {n: (float(s / c) if c else 0.0) for n, s, c in zip(("tentative", "pressure", "final_pressure", "pressure_reconstruction"), sums, cnt)}
+        return dict(value=e2.n_total * args.steps / el / 1e6, unit="million DOF-updates/s", ms_per_step=el / args.steps * 1e3,
+                    krylov_iterations_avg=its, backward_error_tol=float(tol),
+                    note="secondary number: condensed solves stop at |M r| <= tol * |pressure trace| (or at rtol 1e-12); parity tests "
+                         "pass with it (2e-8 against the oracle); not the headline because it is not the reference's stopping rule")
+    finally:
+        del os.environ["HDG_TRACE_BACKWARD_TOL"]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -528,6 +555,10 @@ def main():
             "roofline": roof,
             "timers": timers,
         }
+        if world == 1 and not os.environ.get("HDG_TRACE_BACKWARD_TOL") and not os.environ.get("BENCH_NO_ALT_STOP"):
+            # SECONDARY number, not the headline: the same steps with the normwise backward-error stop of the condensed solves
+            # (Engine::pressure_solve) on a second engine.  The headline above keeps the reference's rule.
+            line["alt_stop_rule"] = alt_stop_rule(build, args, dt, kappa, mp, ssp2_scales)
         if not args.no_cpu_baseline and world == 1:
             cb = cpu_baseline(k)
             # the GPU number at the CPU sample's size ("report DOF-updates/s at that size next to the
