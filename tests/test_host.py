@@ -293,3 +293,40 @@ def test_unit_disk_mesh_and_general_mesh_output(tmp_path):
     vtu = VTKFile(str(tmp_path / "disk.pvd")).write(f)
     txt = open(vtu).read()
     assert f'NumberOfCells="{m.num_cells()}"' in txt and 'Name="f"' in txt
+
+
+@pytest.mark.parametrize("k,level", [(1, 2), (2, 1), (3, 1)])
+def test_general_mesh_host_side_invariants(tmp_path, k, level):
+    """The host side of the general-mesh path (csrc/hdg_general.hpp, hdg_amg.hpp: plain C++, compiled here with g++, no GPU):
+    condensed operator symmetric with the constants as kernel, BDM projection idempotent, the constraint rows of the
+    monolithic system vanish on constants, the P1 prolongation reproduces constants, every level of the smoothed-aggregation
+    hierarchy keeps symmetry / kernel / partition of unity and gets smaller, the dense pseudo-inverse of the coarsest operator
+    inverts on the range, the continuous space has the mesh's volume, projects constants and gives vorticity 2 for a rotation."""
+    import shutil
+    import subprocess
+
+    from incompressibleeulerhdg_amd.mesh import UnitDiskMesh
+
+    gxx = shutil.which("g++")
+    if gxx is None:
+        pytest.skip("no g++")
+    exe = tmp_path / "general_host_check"
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "host", "general_host_check.cpp")
+    subprocess.run([gxx, "-std=c++17", "-O1", "-o", str(exe), src], check=True)
+    m = UnitDiskMesh(level)
+    with open(tmp_path / "mesh.txt", "w") as f:
+        f.write(f"{len(m.vertices)} {len(m.cells)}\n")
+        np.savetxt(f, m.vertices, fmt="%.17g")
+        np.savetxt(f, m.cells, fmt="%d")
+    out = subprocess.run([str(exe), str(tmp_path / "mesh.txt"), str(k)], check=True, capture_output=True, text=True).stdout
+    v = {ln.split()[0]: ln.split()[1] for ln in out.strip().splitlines()}
+    assert "error" not in v, out
+    f = lambda name: float(v[name])
+    assert int(v["nc"]) == 8 * 4 ** level and abs(f("volume") - m.volume) < 1e-12
+    for name in ("S_asym", "S_null", "Pi_idempotent", "mu_row_constant", "psi_row_constant", "P0_constants", "amg_null", "amg_asym",
+                 "amg_P_constants", "coarse_pinv", "cg_M_asym", "cg_projection_rhs_constant", "cg_vorticity_rotation"):
+        assert f(name) < 1e-10, (name, v[name])
+    assert int(v["amg_levels"]) >= 2 and int(v["amg_monotone"]) == 1
+    p = k + 1
+    assert int(v["ncg"]) == int(v["nv"]) + int(v["ne"]) * (p - 1) + int(v["nc"]) * (p - 1) * (p - 2) // 2
+    assert abs(f("cg_volume") - m.volume) < 1e-11
