@@ -297,6 +297,9 @@ __device__ __forceinline__ void mv_acc_ld(const double* __restrict__ A, int LD, 
 #ifndef HDG_LIFT_WAVES
 #define HDG_LIFT_WAVES 1
 #endif
+#ifndef HDG_LIFT_PIPE
+#define HDG_LIFT_PIPE 1
+#endif
 // CHEB (compile time) = with the Chebyshev epilogue: its own instantiation and kernel NAME (profiles, counters).
 template <int K, bool TRANSPOSE, int ADD_BJ, bool CHEB>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(HDG_LIFT_WAVES)))
@@ -321,6 +324,33 @@ void k_edge_lift(Geo g, DevTables T, const double* __restrict__ in,
     load_vel<NU>(r, g.Nc, c, rr);
     mv_acc<N2, N2>(s == 0 ? Dinv0 : Dinv1, rr, y, 1.0);
   }
+  // Forms WITHOUT the Chebyshev epilogue (GMRES tail, BDM projection, transposed lift): the coefficients of neighbour e + 1 are
+  // requested BEFORE the products of neighbour e (double buffer), so that the four groups of loads of a thread (own cell, three
+  // neighbours) are not four dependent round trips: plain hybrid lift 207 -> 171 us at C3 (148 VGPRs, 3 waves / SIMD).  The form
+  // with the fused Chebyshev step keeps the serial order: it needs its 4 waves (125 VGPRs) for the epilogue's streams and
+  // loses 1 % with the double buffer (HDG_LIFT_PIPE=0: serial order everywhere).
+  if constexpr (HDG_LIFT_PIPE && !CHEB && K <= 2) {  // (k >= 3: the matrix-core lift does the work; the per-thread forms keep their registers)
+    long cnb[3];
+    bool hasn[3];
+#pragma unroll
+    for (int e = 0; e < 3; e++) hasn[e] = nbr(s, e, i, j, g, cnb[e]);
+    double xn[2][N2];
+    if (hasn[0]) load_vel<NU>(in, g.Nc, cnb[0], xn[0]);
+#pragma unroll
+    for (int e = 0; e < 3; e++) {
+      const double* __restrict__ Inb = TRANSPOSE ? T.LiftT[1 - s][e] : T.N[1 - s][e];
+      const double* __restrict__ Out =
+          ADD_BJ == 2 ? (s == 0 ? Dinv0 : Dinv1) + e * N2 * NE : (TRANSPOSE ? T.Nt[s][e] : T.Lift[s][e]);
+      if (e + 1 < 3 && hasn[(e + 1) % 3]) load_vel<NU>(in, g.Nc, cnb[(e + 1) % 3], xn[(e + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (hasn[e]) {
+        mv_acc<NE, N2>(Inb, xn[e & 1], down[e], 1.0);
+#pragma unroll
+        for (int a = 0; a < NE; a++) down[e][a] *= 0.5;
+      }
+      mv_acc<N2, NE>(Out, down[e], y, 1.0);
+    }
+  } else {
 #pragma unroll
   for (int e = 0; e < 3; e++) {
     const double* __restrict__ Inb = TRANSPOSE ? T.LiftT[1 - s][e] : T.N[1 - s][e];
@@ -335,6 +365,7 @@ void k_edge_lift(Geo g, DevTables T, const double* __restrict__ in,
       for (int a = 0; a < NE; a++) down[e][a] *= 0.5;
     }
     mv_acc<N2, NE>(Out, down[e], y, 1.0);
+  }
   }
   if (out) store_vel<NU>(out, g.Nc, c, y);
   if (cell_ss) {
