@@ -1170,6 +1170,10 @@ struct Engine {
   }
   // HDG_MFMA_K2 (experiment): the matrix-core kernels at k = 2 as well (north_star: "MFMA at k >= 2")
   static int mfma_min_degree() { static const int d = std::getenv("HDG_MFMA_K2") ? 2 : 3; return d; }
+  bool lift_pair() const {
+    static const bool off = std::getenv("HDG_LIFT_NO_PAIR") != nullptr;
+    return !off && K <= 2 && bs() == 128 && !general;
+  }
   void lift_mfma(const Geo& gx, const double* t0, const double* t1, const double* in, double* out, double* chd_ = nullptr,
                  const double* chx_ = nullptr, double c1 = 0.0, double c2 = 0.0) {
     const dim3 grid(8 * gx.rows_xcd * 2);
@@ -1199,6 +1203,11 @@ struct Engine {
       if (!liftm_plain[0])
         for (int sh = 0; sh < 2; sh++) liftm_plain[sh] = upload(pack_lift_mfma(sh, tab->Lift[sh]));
       lift_mfma(gx, liftm_plain[0], liftm_plain[1], in, out);
+      return;
+    }
+    if (lift_pair()) {
+      if (K == 1) k_edge_lift_pair<1, false, 0, false><<<cell_grid_of(gx), 128, 0, stream>>>(gx, dt, in, out, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, 0.0, nullptr);
+      else k_edge_lift_pair<2, false, 0, false><<<cell_grid_of(gx), 128, 0, stream>>>(gx, dt, in, out, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, 0.0, nullptr);
       return;
     }
     HDG_DISPATCH(k_edge_lift<KK, false, 0, false><<<cell_grid_of(gx), bs(), 0, stream>>>(gx, dt, in, out, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, 0.0, nullptr));
@@ -1242,6 +1251,15 @@ struct Engine {
         // k >= 3: matrix-core kernel with the packed G tables of this stage (GMRES path: plain; Chebyshev path: fused step)
         for (size_t q = 0; q < hybg0.size(); q++)
           if (hybg0[q] == D0) { lift_mfma(gx, liftm_hyb0[q], liftm_hyb1[q], in, out, chd_, chx_, c1, c2); return; }
+      }
+      if (lift_pair()) {  // k <= 2, 128-thread workgroups: both triangles of a square in one workgroup, moments through LDS
+        auto go = [&](auto kk) {
+          constexpr int KK = decltype(kk)::value;
+          if (chd_) k_edge_lift_pair<KK, false, 2, true><<<cell_grid_of(gx), 128, 0, stream>>>(gx, dt, in, out, nullptr, D0, D1, chd_, chx_, c1, c2, ss);
+          else k_edge_lift_pair<KK, false, 2, false><<<cell_grid_of(gx), 128, 0, stream>>>(gx, dt, in, out, nullptr, D0, D1, chd_, chx_, c1, c2, ss);
+        };
+        if (K == 1) go(std::integral_constant<int, 1>{}); else go(std::integral_constant<int, 2>{});
+        return;
       }
       if (chd_) { HDG_DISPATCH(k_edge_lift<KK, false, 2, true><<<cell_grid_of(gx), bs(), 0, stream>>>(gx, dt, in, out, nullptr, D0, D1, chd_, chx_, c1, c2, ss)); }
       else { HDG_DISPATCH(k_edge_lift<KK, false, 2, false><<<cell_grid_of(gx), bs(), 0, stream>>>(gx, dt, in, out, nullptr, D0, D1, chd_, chx_, c1, c2, ss)); }

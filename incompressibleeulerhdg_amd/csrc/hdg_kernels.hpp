@@ -416,6 +416,146 @@ void k_edge_lift(Geo g, DevTables T, const double* __restrict__ in,
 }
 
 // ------------------------------------------------------------------------------------------
+// K1, paired form (k <= 2, 128-thread workgroups): BOTH triangles of 64 squares of a row in one workgroup -- wave 0 the
+// lower-left cells (shape 0), wave 1 the upper-right ones (shape 1; the shape stays wave uniform: scalar table loads) -- and the
+// two waves exchange the EDGE MOMENTS  m_e = In_e x  of their cells through LDS instead of gathering each other's coefficients:
+//   * a cell's neighbours across edges 1 (same square) and 2 (the square to the left / right) live in the other wave: their
+//     moments on the shared edge are what those cells compute for themselves anyway (local edge numbers of the two cells of an
+//     edge agree), so 8 doubles per cell go through LDS where 40 came from global memory, and 2 of the 3 neighbour products
+//     (In_e x_nbr, 80 of 800 FMAs each) are not repeated;
+//   * only the neighbour across edge 0 (the row below / above) is gathered from global memory, and its loads are issued together
+//     with the cell's own: ONE memory round trip per thread where the gather form has four dependent ones (ISA of the shipped
+//     library: four load groups, each followed by its s_waitcnt chain; 45 % of the wave cycles waiting, profiles/r03h_pmc_probe.txt);
+//   * the first / last live lane of a wave, whose edge-2 neighbour lies in the next workgroup, gathers that one cell the old way
+//     (predicated: one lane; its loads are issued with the others).  Measured alternative: the wave forms that one moment together
+//     (lanes 0 .. NU-1 load one pair each, per-lane table columns, butterfly + broadcast: 152 instead of 164 VGPRs) -- slower,
+//     262 / 177 us instead of 237 / 126: the per-lane table loads are one more dependent round trip, and 152 VGPRs are 3 waves too.
+// Same results as k_edge_lift up to the order of two additions per moment (m_nbr - m_own instead of -m_own + m_nbr: identical).
+// ------------------------------------------------------------------------------------------
+template <int K, bool TRANSPOSE, int ADD_BJ, bool CHEB>
+__global__ __launch_bounds__(128) void k_edge_lift_pair(Geo g, DevTables T, const double* __restrict__ in, double* __restrict__ out,
+                                                        const double* __restrict__ r, const double* __restrict__ Dinv0,
+                                                        const double* __restrict__ Dinv1, double* __restrict__ chd_,
+                                                        double* __restrict__ chx, double c1, double c2, double* __restrict__ cell_ss) {
+  constexpr int NU = Dim<K>::NU, NE = Dim<K>::NE, N2 = 2 * NU;
+  __shared__ double ms[2][2][NE][64];  // [shape][edge 1, 2][moment][lane]
+  double* __restrict__ chd = CHEB ? chd_ : nullptr;
+  const int xcd_ = blockIdx.x & 7, q_ = blockIdx.x >> 3;
+  const int jj_ = q_ / (2 * g.nbx), rem_ = q_ - jj_ * 2 * g.nbx;  // rem_: block of 64 squares (2 nbx blocks per row, as before)
+  const int s = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = (int)(threadIdx.x & 63);
+  const int i0 = rem_ * 64, i = i0 + lane;
+  const int r_ = xcd_ * g.rows_xcd + jj_;
+  const int j = launch_row(g, r_);
+  if (jj_ >= g.rows_xcd || r_ >= g.wrows || i0 >= g.nx) return;  // whole workgroup
+  const bool live = i < g.nx;
+  const int ic = live ? i : g.nx - 1;  // clamped: loads stay in bounds, nothing is stored for dead lanes
+  const long c = rowbase(g, s, j) + ic;
+  const int ilast = min(i0 + 63, g.nx - 1);
+  // neighbours: edge 0 (other row), edge 2 of the lane at the end of the wave's range (next workgroup)
+  long cn0 = 0, cnx = 0;
+  const bool has0 = !g.dbg_nonbr && nbr(s, 0, ic, j, g, cn0);
+  const bool has2 = !g.dbg_nonbr && (s == 0 ? (ic > 0 || g.px) : (ic < g.nx - 1 || g.px));
+  const bool outer = live && has2 && (s == 0 ? lane == 0 : ic == ilast);  // its edge-2 neighbour is not in this workgroup
+  if (outer) { long t; nbr(s, 2, ic, j, g, t); cnx = t; }
+  double y[N2], xn0[N2], xnx[N2], down[3][NE];
+  load_vel<NU>(in, g.Nc, c, y);
+#pragma unroll
+  for (int n = 0; n < N2; n++) { xn0[n] = 0.0; xnx[n] = 0.0; }
+  if (has0) load_vel<NU>(in, g.Nc, cn0, xn0);
+  if (outer) load_vel<NU>(in, g.Nc, cnx, xnx);
+  // own moments; edges 1 and 2 are published for the other wave
+#pragma unroll
+  for (int e = 0; e < 3; e++) {
+#pragma unroll
+    for (int a = 0; a < NE; a++) down[e][a] = 0.0;
+    mv_acc<NE, N2>(TRANSPOSE ? T.LiftT[s][e] : T.N[s][e], y, down[e], 1.0);  // + m_own (sign applied below)
+  }
+#pragma unroll
+  for (int a = 0; a < NE; a++) { ms[s][0][a][lane] = down[1][a]; ms[s][1][a][lane] = down[2][a]; }
+  if (ADD_BJ == 1) {
+    double rr[N2];
+    load_vel<NU>(r, g.Nc, c, rr);
+    mv_acc<N2, N2>(s == 0 ? Dinv0 : Dinv1, rr, y, 1.0);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < 3; e++) {
+    const double* __restrict__ Inb = TRANSPOSE ? T.LiftT[1 - s][e] : T.N[1 - s][e];
+    const double* __restrict__ Out =
+        ADD_BJ == 2 ? (s == 0 ? Dinv0 : Dinv1) + e * N2 * NE : (TRANSPOSE ? T.Nt[s][e] : T.Lift[s][e]);
+    double mn[NE];
+    bool has;
+    if (e == 0) {
+      has = has0;
+#pragma unroll
+      for (int a = 0; a < NE; a++) mn[a] = 0.0;
+      mv_acc<NE, N2>(Inb, xn0, mn, 1.0);
+    } else if (e == 1) {
+      has = !g.dbg_nonbr;
+#pragma unroll
+      for (int a = 0; a < NE; a++) mn[a] = ms[1 - s][0][a][lane];
+    } else {
+      has = has2;
+      // shape 0: the upper-right cell of the square to the left; shape 1: the lower-left cell of the square to the right
+      const int ln = s == 0 ? max(lane - 1, 0) : min(lane + 1, 63);
+#pragma unroll
+      for (int a = 0; a < NE; a++) mn[a] = ms[1 - s][1][a][ln];
+      if (__builtin_amdgcn_ballot_w64(outer)) {  // at most one lane per wave: the neighbour in the next workgroup, gathered
+        double mx[NE];
+#pragma unroll
+        for (int a = 0; a < NE; a++) mx[a] = 0.0;
+        mv_acc<NE, N2>(Inb, xnx, mx, 1.0);
+#pragma unroll
+        for (int a = 0; a < NE; a++) mn[a] = outer ? mx[a] : mn[a];
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < NE; a++) down[e][a] = has ? 0.5 * (mn[a] - down[e][a]) : -down[e][a];
+    mv_acc<N2, NE>(Out, down[e], y, 1.0);
+  }
+  if (!live) return;
+  if (out) store_vel<NU>(out, g.Nc, c, y);
+  if (cell_ss) {
+    double ss = 0.0;
+#pragma unroll
+    for (int n = 0; n < N2; n++) ss = fma(y[n], y[n], ss);
+    cell_ss[c] = ss;
+  }
+  if (chd) {  // Chebyshev step in three-term form (see k_edge_lift)
+    const bool rd = (c1 != 0.0);
+    const VelBuf Bp(chd), Bx(chx);
+    const unsigned lane_b = (unsigned)c * 16u;
+    constexpr int NCH = NU >= 10 ? 2 : 1;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ch++) {
+      const int m_lo = ch * NU / NCH, m_hi = (ch + 1) * NU / NCH;
+      hdg_d2 pp[NU], xx[NU];
+#pragma unroll
+      for (int m = 0; m < NU; m++)
+        if (m >= m_lo && m < m_hi) xx[m] = (HDG_LIFT_NT & 1) ? Bx.ld_nt(pair_bytes(m, g.Nc), lane_b) : Bx.ld(pair_bytes(m, g.Nc), lane_b);
+      if (rd) {
+#pragma unroll
+        for (int m = 0; m < NU; m++)
+          if (m >= m_lo && m < m_hi) pp[m] = (HDG_LIFT_NT & 2) ? Bp.ld_nt(pair_bytes(m, g.Nc), lane_b) : Bp.ld(pair_bytes(m, g.Nc), lane_b);
+      } else {
+#pragma unroll
+        for (int m = 0; m < NU; m++)
+          if (m >= m_lo && m < m_hi) pp[m] = xx[m];
+      }
+#pragma unroll
+      for (int m = 0; m < NU; m++)
+        if (m >= m_lo && m < m_hi) {
+          hdg_d2 xn1;
+          xn1.x = fma(c1, xx[m].x - pp[m].x, fma(c2, y[m], xx[m].x));
+          xn1.y = fma(c1, xx[m].y - pp[m].y, fma(c2, y[NU + m], xx[m].y));
+          if (HDG_LIFT_NT & 4) Bp.st_nt(pair_bytes(m, g.Nc), lane_b, xn1); else Bp.st(pair_bytes(m, g.Nc), lane_b, xn1);
+        }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // K1 on the matrix cores (k >= 3).  At high order the per-thread formulation above is limited by operand
 // delivery (tables through scalar loads, 228-256 VGPRs, 0.8-1.6 TB/s); the same three contractions as MFMA:
 //   (1) own normal moments      d   = -W x              W: packed (edge, moment) rows x 2NU
