@@ -105,7 +105,7 @@ def roofline_block(eng, args, nx, k, world, ktimers=None, timed_where="the timed
     kernel are separate instantiations with their own names (last template argument), so profiles tell them apart:
       Chebyshev phase (default):  k_adv_apply<K, true> / k_adv_mfma<K, true>: residual form t = b - (I - gamma F(Q*)) x
                                   (reads x, Q*, b, writes t: 4 vectors of 8 N_Q bytes, SURVEY.md section 8d);
-                                  k <= 2: k_edge_lift<K, false, 2, true> with the fused Chebyshev step (reads t, x_n, x_{n-1},
+                                  k <= 2: k_edge_lift_pair<K, false, 2, true> (nx <= 64: k_edge_lift<...>) with the fused Chebyshev step (reads t, x_n, x_{n-1},
                                   writes x_{n+1}: 4 vectors);  k >= 3: k_edge_lift_mfma<K, true>, the matrix-core lift with the same
                                   fused step (4 vectors; HDG_MFMA_CHEB_UNFUSED: plain lift + separate k_cheb_update);
       GMRES phase:                k_adv_apply<K, false> / k_adv_mfma<K, false> (reads x, Q*, writes y: 3 vectors) and the plain
@@ -137,8 +137,9 @@ def roofline_block(eng, args, nx, k, world, ktimers=None, timed_where="the timed
                 if cfg["workload"] == {"nx": nx, "degree": k}:
                     kn = cfg["kernels"]
                     fm = "true" if cheb else "false"
+                    lk = lift_kernel_name(k, nx)
                     for key, names in (("adv", (f"k_adv_apply<{k}, {fm}>", f"k_adv_mfma<{k}, {fm}>")),
-                                       ("lift", (f"k_edge_lift<{k}, false, 2, {fm}>", f"k_edge_lift_mfma<{k}, {fm}>"))):
+                                       ("lift", (f"{lk}<{k}, false, 2, {fm}>", f"k_edge_lift_mfma<{k}, {fm}>"))):
                         for nm in names:
                             if nm in kn and (k <= 2) == ("mfma" not in nm):
                                 pmc[key] = kn[nm]["hbm_bytes"]
@@ -154,7 +155,8 @@ def roofline_block(eng, args, nx, k, world, ktimers=None, timed_where="the timed
         (ms_lift, n_lift), (ms_adv, n_adv) = in_place("kernel_lift", ms_lift_alone), in_place("kernel_advection", ms_adv_alone)
         nv_lift = ((4 if hybrid else 6) if cheb else 2)
         nv_adv = 4 if cheb else 3
-        lift_name = (f"k_edge_lift<{k}, false, {2 if hybrid else 1}, {'true' if cheb else 'false'}>" + (" (lift + fused Chebyshev step)" if cheb else ""))
+        lift_name = (f"{lift_kernel_name(k, nx) if hybrid else 'k_edge_lift'}<{k}, false, {2 if hybrid else 1}, {'true' if cheb else 'false'}>"
+                     + (" (lift + fused Chebyshev step)" if cheb else ""))
         adv_name = f"k_adv_apply<{k}, {'true' if cheb else 'false'}>" + (" (residual form b - (I - gamma F) x)" if cheb else "")
         cand = {"lift": (lift_name, 8.0 * nv_lift * NQ, ms_lift), "adv": (adv_name, 8.0 * nv_adv * NQ, ms_adv)}
         dom = "adv" if ms_adv >= ms_lift else "lift"
@@ -333,6 +335,12 @@ def reassembly_split(eng, k, nx, cb, gpu_s_per_step):
                 cpu_share_of_step=(cpu_extra / cpu_s_per_step) if cpu_s_per_step else None,
                 note="lower bounds at peak FP64 rates: not re-assembling is worth at least these shares on either side; "
                      "both sides of the reported GPU/CPU ratio skip it, so the ratio is kernel + solver efficiency only")
+
+
+def lift_kernel_name(k, nx):
+    """The per-thread lift runs in its paired form (both triangles of a square in one workgroup, edge moments through LDS) at
+    k <= 2 on meshes with more than 64 columns (Engine::lift_pair)."""
+    return "k_edge_lift_pair" if (k <= 2 and nx > 64 and not os.environ.get("HDG_LIFT_NO_PAIR")) else "k_edge_lift"
 
 
 def alt_stop_rule(build, args, dt, kappa, mp, ssp2_scales, tol="1e-15"):
