@@ -1170,10 +1170,8 @@ struct Engine {
   }
   // HDG_MFMA_K2 (experiment): the matrix-core kernels at k = 2 as well (north_star: "MFMA at k >= 2")
   static int mfma_min_degree() { static const int d = std::getenv("HDG_MFMA_K2") ? 2 : 3; return d; }
-  bool lift_pair() const {
-    static const bool off = std::getenv("HDG_LIFT_NO_PAIR") != nullptr;
-    return !off && K <= 2 && bs() == 128 && !general;
-  }
+  const bool lift_pair_off = std::getenv("HDG_LIFT_NO_PAIR") != nullptr;  // read when an engine is built (tests compare the two forms)
+  bool lift_pair() const { return !lift_pair_off && K <= 2 && bs() == 128 && !general; }
   void lift_mfma(const Geo& gx, const double* t0, const double* t1, const double* in, double* out, double* chd_ = nullptr,
                  const double* chx_ = nullptr, double c1 = 0.0, double c2 = 0.0) {
     const dim3 grid(8 * gx.rows_xcd * 2);

@@ -324,3 +324,44 @@ def test_schur_matrix_core_kernels_tiles(hip_lib, k, nx, mfma_condense, monkeypa
     e.finish_step()
     _, gp, gl = e.get_field(_lib.HDG_STATE_CURRENT)
     assert _relerr(gp, p) < TOL and _relerr(gl, lam) < TOL
+
+
+@pytest.mark.parametrize("periodic", [False, True])
+@pytest.mark.parametrize("k,nx", [(1, 72), (2, 128), (2, 200), (1, 130)])
+def test_paired_lift_kernel_equals_the_gather_form(hip_lib, monkeypatch, k, nx, periodic):
+    """k_edge_lift_pair (both triangles of a square in one workgroup, edge moments through LDS, hdg_kernels.hpp) against the
+    gather form k_edge_lift on meshes with full and partial 64-square blocks, with and without periodic wrap-around: the BDM
+    projection and the hybrid preconditioner inside a tentative-velocity solve (same sums, two additions per moment reordered)."""
+    from incompressibleeulerhdg_amd._lib import Engine
+    from oracle.hdg_oracle import TABLEAUX
+
+    tb = TABLEAUX["imex_ssp2_332"]
+
+    def make(no_pair):
+        if no_pair:
+            monkeypatch.setenv("HDG_LIFT_NO_PAIR", "1")
+        else:
+            monkeypatch.delenv("HDG_LIFT_NO_PAIR", raising=False)
+        return Engine(nx=nx, degree=k, dt=0.25 / nx, nstages=3, a_expl=tb["a_expl"], a_impl=tb["a_impl"], b_expl=tb["b_expl"],
+                      b_impl=tb["b_impl"], c_expl=tb["c_expl"], periodic=periodic, length=1.0)
+
+    ea, eb = make(False), make(True)
+    rng = np.random.default_rng(5 + k)
+    Q = rng.standard_normal(ea.shape_Q)
+    Pa, Pb = ea.project_bdm_nodal(Q), eb.project_bdm_nodal(Q)
+    assert np.max(np.abs(Pa - Pb)) < 1e-12 * np.max(np.abs(Pb))
+    assert np.max(np.abs(Pa - Q)) > 1e-3  # the projection changes random data
+    # one whole step: hybrid lift with and without the fused Chebyshev step inside the tentative-velocity solves
+    S = lambda z: np.sin(2 * np.pi * z)
+    C = lambda z: np.cos(2 * np.pi * z)
+    xq, xp = ea.node_coordinates()
+    Q0 = np.stack([S(xq[:, 0]) * C(xq[:, 1]), -C(xq[:, 0]) * S(xq[:, 1])], axis=-1)
+    out = []
+    for e in (ea, eb):
+        e.set_state(Q0, 0.25 * (C(2 * xp[:, 0]) + C(2 * xp[:, 1])))
+        e.reconstruct_trace()
+        for sl in range(4):
+            e.set_forcing_scale(sl, 0.0)
+        e.step()
+        out.append(e.get_field(0)[0].copy())
+    assert np.max(np.abs(out[0] - out[1])) < 2e-8 * np.max(np.abs(out[1]))
