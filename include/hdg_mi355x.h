@@ -178,6 +178,15 @@ int hdg_implicit_step(hdg_handle* h, int* its_tentative, int* its_pressure);
 /* iteration statistics accumulated since the last reset (hdg_imex.py:90-93,648-658):
  * sums[4] / counts[4] for tentative, pressure, final pressure, pressure reconstruction */
 int hdg_get_iteration_stats(hdg_handle* h, double* sums, long* counts, int reset);
+/* Events of the condensed (trace) solves since the last reset.  The reference's KSP (hdg_imex.py:136-137: rtol 1e-12,
+ * PETSc max_it 10000) either converges or raises; SURVEY.md 5.3: "Krylov divergence / max-it is an error code, never
+ * silent".  The single-reduction CG of this library replaces its residual by the true one (r = b - T x, recurrences
+ * restarted) when the recurrence residual stalls within three decades of the target or p.Ap turns non-positive, and ends
+ * a solve only if the TRUE preconditioned residual meets rtol or lies at its rounding floor 32 eps |x|:
+ *   events[0] residual replacements, events[1] solves ended at the rounding floor, events[2..3] reserved (0).
+ * A third symptom within one solve returns HDG_ERR_NOT_CONVERGED. */
+#define HDG_N_SOLVER_EVENTS 4
+int hdg_get_solver_events(hdg_handle* h, long* events, int reset);
 
 /* Device-side timers with the labels of the reference's PerformanceLog (src/auxilliary/logging.py:11-60, used at
  * hdg_imex.py:257,274,551,564,601): index 0 timestep, 1 bdm_projection, 2 tentative_velocity_solve, 3 pressure_solve,
@@ -193,6 +202,10 @@ int hdg_get_timers(hdg_handle* h, double* total_ms, double* sumsq_ms, long* ncal
  * Chebyshev step / plain) -- bracketed by its own event pair IN PLACE, i.e. with the operands and cache state of the
  * solve.  Recorded only while switched on (two event records per launch: about 1 % of a C3 step). */
 int hdg_set_kernel_timing(hdg_handle* h, int on);
+/* Transport of a distributed handle as the transport itself reports it: this rank, the number of ranks of the strip
+ * partition, the size of the communicator (RCCL: ncclCommCount; must equal nranks) and its name ("self", "rccl", "shm";
+ * name16: at least 16 bytes).  No reference counterpart (the reference has no explicit communication, SURVEY.md 2.3). */
+int hdg_get_comm_info(const hdg_handle* h, int* rank, int* nranks, int* transport_ranks, char* name16);
 /* Launch census since the last reset (no reference counterpart; SURVEY.md section 8(d): "roofline.achieved = sum_k calls_k *
  * bytes_k / elapsed / BW_peak with calls_k printed alongside"): per kernel class the number of launches and the ALGORITHMIC
  * bytes they moved -- every logical vector read or written once per launch, 8 B per owned entry, shared operator tables
@@ -201,12 +214,19 @@ int hdg_set_kernel_timing(hdg_handle* h, int on);
  * 3 weak_divergence, 4 condense (K5), 5 trace_apply (K6), 6 trace_smooth (K7: smoother steps on the trace space),
  * 7 backsub (K8), 8 vertex_multigrid (K7: P1 V-cycle and transfers), 9 vector_update (K9), 10 dot (K9),
  * 11 copy_fill, 12 other (scalar kernels, trace reconstruction, constraint rows). */
-/* Transport of a distributed handle as the transport itself reports it: this rank, the number of ranks of the strip
- * partition, the size of the communicator (RCCL: ncclCommCount; must equal nranks) and its name ("self", "rccl", "shm";
- * name16: at least 16 bytes).  No reference counterpart (the reference has no explicit communication, SURVEY.md 2.3). */
-int hdg_get_comm_info(const hdg_handle* h, int* rank, int* nranks, int* transport_ranks, char* name16);
 #define HDG_N_LAUNCH_CLASSES 13
 int hdg_get_launch_stats(hdg_handle* h, long* calls, double* bytes, int reset);
+/* Which form of its kernels this handle launches (no reference counterpart; bench.py labels its roofline block and looks
+ * up the PMC traffic by these instead of re-deriving the engine's rules):
+ *   forms[0] edge lift (BDM projection / hybrid preconditioner): 0 gather form k_edge_lift, 1 paired form k_edge_lift_pair,
+ *            2 matrix-core k_edge_lift_mfma, 3 assembled operator (general meshes);
+ *   forms[1] advection operator: 0 per-thread k_adv_apply, 2 matrix-core k_adv_mfma, 3 general-mesh kernel k_g_adv;
+ *   forms[2] trace preconditioner: 0 row-stencil kernels k_trace_smooth, 1 LDS-tiled k_trace_pre_tile / k_trace_post_tile,
+ *            3 general meshes;
+ *   forms[3] local Schur kernels (back-substitution, pressure gradient, weak divergence): 0 per-thread, 2 matrix-core,
+ *            3 assembled operators (general meshes). */
+#define HDG_N_KERNEL_FORMS 4
+int hdg_get_kernel_forms(hdg_handle* h, int* forms);
 
 /* ---- passive tracer.  Explicit DG transport of a scalar in DG_k by the L2 projection of
  * the stage velocity onto [CG_{k+1}]^2 (common.py:110-129): q_i = q_0 + dt sum_{j<i} a_expl[i,j] M^-1 T(q_j, P(Q_i))

@@ -121,6 +121,8 @@ SIGNATURES = {
     "hdg_run_separable": [_h, C.c_int, _dp],
     "hdg_implicit_step": [_h, _ip, _ip],
     "hdg_get_iteration_stats": [_h, _dp, _lp, C.c_int],
+    "hdg_get_solver_events": [_h, _lp, C.c_int],
+    "hdg_get_kernel_forms": [_h, _ip],
     "hdg_rccl_selftest": [C.c_int, C.c_int, _dp],
     "hdg_get_timers": [_h, _dp, _dp, _lp, C.c_int],
     "hdg_set_kernel_timing": [_h, C.c_int],
@@ -367,6 +369,18 @@ class Engine:
         cnt = np.zeros(4, dtype=np.int64)
         self._ck(self.lib.hdg_get_iteration_stats(self.h, _ptr(sums), cnt.ctypes.data_as(_lp), 1 if reset else 0))
         return sums, cnt
+
+    def solver_events(self, reset=False):
+        """Residual replacements / rounding-floor exits of the condensed solves since the last reset (dict)."""
+        ev = np.zeros(4, dtype=np.int64)
+        self._ck(self.lib.hdg_get_solver_events(self.h, ev.ctypes.data_as(_lp), 1 if reset else 0))
+        return {"cg_residual_replacements": int(ev[0]), "cg_floor_exits": int(ev[1])}
+
+    def kernel_forms(self):
+        """Which form of its kernels the engine launches (hdg_get_kernel_forms): dict of small integers."""
+        f = (C.c_int * 4)()
+        self._ck(self.lib.hdg_get_kernel_forms(self.h, f))
+        return {"lift": f[0], "advection": f[1], "trace_precond": f[2], "schur": f[3]}
 
     # --- passive tracer, continuous-space diagnostics
     def set_tracer(self, q):

@@ -529,7 +529,7 @@ struct Engine {
     overlap_on = !std::getenv("HDG_NO_OVERLAP") && (std::strcmp(comm->name(), "rccl") == 0 || std::getenv("HDG_OVERLAP") != nullptr);
     if (periodic && comm->size > 1) throw std::string("the periodic mesh is implemented for a single rank");
     if (periodic && (c.nx % 2 != 0)) throw std::string("the periodic mesh needs an even nx (red-black coarse-grid sweeps)");
-    if (periodic && g.ny < GH) throw std::string("the periodic mesh needs at least 4 cell rows");
+    if (periodic && g.ny < 4) throw std::string("the periodic mesh needs at least 4 cell rows");
     if (periodic) {
       // y-periodicity without touching a kernel: the strip pretends to lie in the middle of a taller mesh (no physical
       // boundary test in y fires, the top H row is a ghost copy of the bottom one like on a rank below another) and its
@@ -579,8 +579,8 @@ struct Engine {
   }
   ~Engine() {
     if (debug_on() && comm && comm->rank == 0)
-      fprintf(stderr, "[comm] halo exchanges: velocity %ld, pressure %ld, trace %ld, vertex rows %ld (%ld of them beside an interior launch); all-reduces %ld; all-gathers %ld\n",
-              n_halo[0], n_halo[1], n_halo[2], n_halo_mg, n_overlapped, n_reduce, n_gather);
+      fprintf(stderr, "[comm] halo exchanges: velocity %ld, pressure %ld, trace %ld, vertex rows %ld (%ld of them beside an interior launch); all-reduces %ld; all-gathers %ld; tiled trace preconditioner applications %ld\n",
+              n_halo[0], n_halo[1], n_halo[2], n_halo_mg, n_overlapped, n_reduce, n_gather, n_tile_precond);
     if (flow_check && comm && comm->rank == 0)
       fprintf(stderr, "[flow check] %ld skipped exchanges verified, worst relative deviation %.3e\n", fc_count, fc_worst);
     release();
@@ -699,6 +699,7 @@ struct Engine {
   bool halo_on = true;  // switched off while timing bare kernel launches (hdg_time_kernel is not collective)
   long n_halo[3] = {0, 0, 0}, n_reduce = 0, n_gather = 0;  // communication census (HDG_DEBUG, printed at destruction)
   long n_halo_mg = 0;  // vertex-row exchanges of the distributed V-cycle level (their own counter: not pressure halos)
+  long n_tile_precond = 0;  // applications of the LDS-tiled trace preconditioner (census; the multi-rank tests assert it ran)
   // ------------------------------------------------------------------ launch census (hdg_get_launch_stats)
   // Launches and ALGORITHMIC bytes per kernel class: every logical vector read or written once per launch, 8 B per OWNED
   // entry (no ghost / padding rows), shared operator tables free -- SURVEY.md section 8(d).  bench.py's whole-step roofline is
@@ -789,7 +790,7 @@ struct Engine {
   // fused smoother step) reads its input one row beyond the rows it computes: it is launched over as many ghost rows as
   // its inputs allow (Geo::elo / ehi) and its result is valid there; pointwise kernels and the whole-array vector
   // updates pass the validity of their inputs on.  Only a stencil input with NO valid ghost row triggers an exchange,
-  // fl.Dx rows deep.  Dx = GH = 4:
+  // fl.Dx rows deep.  Dx = DX_DEFAULT = 4 (the arrays carry GH = 6 ghost rows: the tiled trace preconditioner exchanges 5):
   //   velocity: x_n exchanged -> b - A x_n on 3 ghost rows -> lift + Chebyshev step on 2 -> operator on 1 -> lift on 0:
   //             one exchange per TWO iterations (the odd iterates stay valid on 2 rows, which the three-term step needs);
   //   trace CG: z exchanged -> w = T z on 3 -> r on 3 -> pre-smoother 3 -> 2 -> coarse correction on 2 -> post-smoother
@@ -819,7 +820,7 @@ struct Engine {
       static const bool off = std::getenv("HDG_NO_EXT") != nullptr;
       if (E.fl.nest++ == 0) {
         E.fl.v.clear();
-        E.fl.Dx = (off || E.comm->size == 1 || E.periodic || !E.halo_on) ? 1 : std::min(GH, E.g.ny);
+        E.fl.Dx = (off || E.comm->size == 1 || E.periodic || !E.halo_on) ? 1 : std::min(DX_DEFAULT, E.g.ny);
       }
     }
     ~FlowScope() noexcept(false) {
@@ -1677,6 +1678,13 @@ struct Engine {
       for (int q = 0; q < nout; q++) res[off + q] = h_res[q];
     }
   }
+  // second stage of a reduction whose per-workgroup partials a kernel left in part[block * nout + q] (the tile kernels of the
+  // trace preconditioner), summed over the ranks; the results stay in d_res
+  void reduce_parts_allreduce(int nblocks, int nout, const double* part) {
+    k_reduce_parts<<<nout, 256, 0, stream>>>(nblocks, nout, part, d_res);
+    comm->allreduce_sum(d_res, nout, stream);
+    n_reduce++;
+  }
   double dot(long n, const double* a, const double* b, int kind) {
     double r;
     multidot(n, a, {b}, &r, kind);
@@ -2341,6 +2349,11 @@ struct Engine {
       for (int l = lev; l < (int)mg_n.size() && tl.nlev < 8; l++) { tl.n[tl.nlev++] = mg_n[l]; tot += (long)(mg_n[l] + 1) * (mg_n[l] + 1); }
       if (tot <= HDG_P1_TAIL_MAX && lev + tl.nlev == (int)mg_n.size()) {
         tally(LC_MG, 16.0 * tot);
+        if (tail_M && lev == tail_lev) {  // the same linear map as one dense matrix (k_p1_dense_tail)
+          const int N = (n + 1) * (n + 1);
+          k_p1_dense_tail<<<(N + 3) / 4, 256, 0, stream>>>(N, tail_pitch, tail_M, mg_b[lev], mg_x[lev]);
+          return;
+        }
         k_p1_vcycle_tail<<<1, 1024, 0, stream>>>(tl, mg_b[lev], mg_x[lev], nsw, ncoarse);
         return;
       }
@@ -2387,6 +2400,37 @@ struct Engine {
     p1_smooth(lev, nsw, true);
   }
   void run_vcycle() { if (periodic) vcycle_periodic(0); else vcycle(0); }
+  // Dense form of the V-cycle tail (k_p1_dense_tail): column c of M = the tail kernel applied to the c-th unit vector.
+  // Built once per engine (~1100 launches of the one-workgroup kernel, ~40 ms); HDG_MG_NO_DENSE_TAIL keeps the tail kernel.
+  double* tail_M = nullptr;
+  int tail_lev = -1, tail_pitch = 0;
+  void build_dense_tail() {
+    static const bool off = std::getenv("HDG_MG_NO_DENSE_TAIL") != nullptr || std::getenv("HDG_MG_NO_TAIL") != nullptr;
+    if (off || periodic || general || mg_n.empty()) return;
+    int lev = 0;
+    while (lev < (int)mg_n.size() && mg_n[lev] > 32) lev++;
+    if (lev >= (int)mg_n.size() - 1) return;  // no tail, or a single level: nothing to gain
+    long tot = 0;
+    for (int l = lev; l < (int)mg_n.size(); l++) tot += (long)(mg_n[l] + 1) * (mg_n[l] + 1);
+    if (tot > HDG_P1_TAIL_MAX || (int)mg_n.size() - lev > 8) return;
+    const int N = (mg_n[lev] + 1) * (mg_n[lev] + 1), pitch = (N + 1) & ~1;
+    double* MT = dalloc((long)N * pitch);
+    double* M = dalloc((long)N * pitch);
+    zero(mg_b[lev], N);
+    for (int c = 0; c < N; c++) {
+      k_fill<<<1, 1, 0, stream>>>(1, mg_b[lev] + c, 1.0);
+      vcycle(lev);  // tail_M is still null: the tail kernel
+      HIPCHECK(hipMemcpyAsync(MT + (long)c * pitch, mg_x[lev], sizeof(double) * N, hipMemcpyDeviceToDevice, stream));
+      k_fill<<<1, 1, 0, stream>>>(1, mg_b[lev] + c, 0.0);
+    }
+    k_transpose_sq<<<dim3((N + 255) / 256, N), 256, 0, stream>>>(N, pitch, MT, M);
+    HIPCHECK(hipStreamSynchronize(stream));
+    lc_calls[LC_MG] -= N; lc_bytes[LC_MG] -= 16.0 * tot * N;  // set-up launches are not part of the census
+    lc_calls[LC_COPY] -= 1; lc_bytes[LC_COPY] -= bvec((long)N);
+    HIPCHECK(hipFree(MT));
+    allocs.erase(std::find(allocs.begin(), allocs.end(), (void*)MT));
+    tail_M = M; tail_lev = lev; tail_pitch = pitch;
+  }
   // ---- strip partition: the finest vertex grid stays distributed, the rest of the V-cycle is replicated.
   // The replicated cycle (every rank gathers the whole (nx+1)^2 right-hand side, 8.4 MB at C3, and runs every level)
   // does not shrink with the number of ranks.  Here each rank keeps its ny+1 vertex rows of level 0:
@@ -2456,12 +2500,32 @@ struct Engine {
   // z = M r for the condensed system
   // LDS-tiled form of the two smoother applications (hdg_trace_tile.hpp): single rank, non-periodic structured mesh,
   // two Chebyshev steps.  HDG_TRACE_NO_TILE: the five row-stencil launches of before.
+  static constexpr int TILE_HALO_R = 5;  // ghost rows of r the tiled preconditioner reads on a strip (pre: 3 computed + 2 halo)
   bool use_trace_tile() const {
     static const bool off = std::getenv("HDG_TRACE_NO_TILE") != nullptr;
     static const int nsm = std::getenv("HDG_TRACE_SMOOTH_ITS") ? std::atoi(std::getenv("HDG_TRACE_SMOOTH_ITS")) : 2;
     static const bool fuse = !std::getenv("HDG_TRACE_NO_FUSE");
+    static const bool strips = !std::getenv("HDG_TRACE_NO_TILE_STRIPS");  // round 4: the tile kernels on a strip partition too
     // k = 4: the post kernel needs 274 VGPRs (15 trace values per corner and stage): 5.88 instead of 5.65 ms per solve at 512^2
-    return !off && fuse && nsm == 2 && cfg.trace_precond == 1 && comm->size == 1 && !periodic && !general && halo_on && K <= 3;
+    return !off && fuse && nsm == 2 && cfg.trace_precond == 1 && !periodic && !general && halo_on && K <= 3 &&
+           (comm->size == 1 || (strips && g.ny >= TILE_HALO_R));
+  }
+  // vertex-grid correction of the trace preconditioner: mg_b[0] <- restriction of `res` (owned edges), one V-cycle, result in
+  // mg_x[0] (global vertex numbering; on a strip valid on the rank's vertex rows and the 3 rows around them)
+  void coarse_correction(const double* res) {
+    const int partial = mg_gather ? 1 : 0;
+    tally(LC_MG, bL() + 8.0 * (g.nx + 1.0) * (g.ny + 1.0));
+    k_trace_to_p1<<<corner_grid_all(), bs(), 0, stream>>>(g_all, NL, res, mg_b[0], dt.elen[0], dt.elen[2], dt.elen[1], partial);
+    if (mg_distributed()) { vcycle_distributed_top(); return; }
+    if (mg_gather) {
+      // every rank contributes its (ny+1) vertex rows; one kernel assembles the global vector from the blocks
+      const long blk = (long)(g.ny + 1) * (g.nx + 1);
+      comm->allgather(mg_b[0] + (long)g.joff * (g.nx + 1), mg_gather, (size_t)blk, stream);
+      n_gather++;
+      const long nvtx = ((long)comm->size * g.ny + 1) * (g.nx + 1);
+      k_p1_assemble<<<vec_blocks(nvtx), 256, 0, stream>>>(comm->size, g.ny, g.nx + 1, mg_gather, mg_b[0], partial);
+    }
+    run_vcycle();
   }
   // returns true when w_out has received T z (the operator application the single-reduction CG needs next); with
   // dots_out set as well, d_res then holds (z,n), (z,r), (z,z), (z,w), (n,r) (the multi-dot of that CG: *dots_out = true)
@@ -2479,16 +2543,24 @@ struct Engine {
       const double theta = 0.5 * (cheb_lmax + cheb_lmin), delta = 0.5 * (cheb_lmax - cheb_lmin), sigma1 = theta / delta;
       const double rho = 1.0 / sigma1, rn = 1.0 / (2.0 * sigma1 - rho), c0 = 1.0 / theta, c1 = rn * rho, c2 = 2.0 * rn / delta;
       const double nvtx = 8.0 * (g.nx + 1.0) * (g.ny + 1.0);
+      // strip partition: the ONE exchange of a CG iteration -- r, 5 ghost rows deep (the pre kernel computes z on 3 ghost rows
+      // towards every neighbour from r on 5; the post kernel then finds its halo of z and r locally)
+      const bool has_lo = comm->size > 1 && comm->rank > 0, has_hi = comm->size > 1 && comm->rank < comm->size - 1;
+      if (comm->size > 1) {
+        if (fl.get(r) < TILE_HALO_R) { halo_L(r, TILE_HALO_R); fl.set(r, TILE_HALO_R); }
+        else if (flow_check) flow_check_input(r, FL, TILE_HALO_R);
+      }
       auto launch = [&](auto kk) {
         constexpr int KK = decltype(kk)::value;
         typedef TraceTile<KK> TT;
-        const int ntx = (g.nx + 1 + TT::TW - 1) / TT::TW, nty = (g.ny + 1 + TT::TH - 1) / TT::TH;
-        const int grid = 8 * ((ntx * nty + 7) / 8);  // XCD-aware tile order (hdg_trace_tile.hpp: HDG_TILE_OF_BLOCK)
+        TileRows pre{has_lo ? -3 : 0, g.nyc + (has_hi ? 3 : 0), 0, 0}, post{0, g.nyc, -3, g.nyc + 3};
+        pre.rlo = pre.jlo - 2; pre.rhi = pre.jhi + 2;
+        const int ntx = (g.nx + 1 + TT::TW - 1) / TT::TW;
+        const int nty_pre = (pre.jhi - pre.jlo + TT::TH - 1) / TT::TH, nty = (post.jhi - post.jlo + TT::TH - 1) / TT::TH;
+        const int grid_pre = 8 * ((ntx * nty_pre + 7) / 8), grid = 8 * ((ntx * nty + 7) / 8);  // XCD-aware tile order (HDG_TILE_OF_BLOCK)
         tally(LC_TRACE_SMOOTH, 3 * bL());
-        k_trace_pre_tile<KK><<<grid, TT::NTHREADS, 0, stream>>>(ntx, nty, g, pdt(), r, c0, c1, c2, ch_d, wL2);
-        tally(LC_MG, bL() + nvtx);
-        k_trace_to_p1<<<corner_grid_all(), bs(), 0, stream>>>(g_all, NL, wL2, mg_b[0], dt.elen[0], dt.elen[2], dt.elen[1], 0);
-        run_vcycle();
+        k_trace_pre_tile<KK><<<grid_pre, TT::NTHREADS, 0, stream>>>(ntx, nty_pre, g, pre, pdt(), r, c0, c1, c2, ch_d, wL2);
+        coarse_correction(wL2);
         tally(LC_TRACE_SMOOTH, (w_out ? 4 : 3) * bL() + nvtx);
         const long nblk = (long)ntx * nty;
         double* part = nullptr;
@@ -2498,14 +2570,14 @@ struct Engine {
           part = tile_part;
         }
         if (part)
-          k_trace_post_tile<KK, true><<<grid, TT::NTHREADS, 0, stream>>>(ntx, nty, g, pdt(), ch_d, r, mg_x[0], std::sqrt(dt.elen[0]), std::sqrt(dt.elen[2]),
+          k_trace_post_tile<KK, true><<<grid, TT::NTHREADS, 0, stream>>>(ntx, nty, g, post, pdt(), ch_d, r, mg_x[0], std::sqrt(dt.elen[0]), std::sqrt(dt.elen[2]),
                                                                          std::sqrt(dt.elen[1]), c0, c1, c2, z, w_out, part);
         else
-          k_trace_post_tile<KK, false><<<grid, TT::NTHREADS, 0, stream>>>(ntx, nty, g, pdt(), ch_d, r, mg_x[0], std::sqrt(dt.elen[0]), std::sqrt(dt.elen[2]),
+          k_trace_post_tile<KK, false><<<grid, TT::NTHREADS, 0, stream>>>(ntx, nty, g, post, pdt(), ch_d, r, mg_x[0], std::sqrt(dt.elen[0]), std::sqrt(dt.elen[2]),
                                                                           std::sqrt(dt.elen[1]), c0, c1, c2, z, w_out, nullptr);
         if (part) {
           tally(LC_OTHER, 0.0);
-          k_reduce_parts<<<5, 256, 0, stream>>>((int)nblk, 5, part, d_res);
+          reduce_parts_allreduce((int)nblk, 5, part);  // second reduction stage (+ the all-reduce across ranks) -> d_res
           *dots_out = true;
         }
       };
@@ -2516,6 +2588,7 @@ struct Engine {
         default: launch(std::integral_constant<int, 4>{}); break;
       }
       fl.set(z, 0); fl.set(w_out, 0);
+      n_tile_precond++;
       return w_out != nullptr;
     }
     if (general) {
@@ -2540,22 +2613,7 @@ struct Engine {
       cheb_smooth(r, z, false, nsm);
       return false;
     }
-    tally(LC_MG, bL() + 8.0 * (g.nx + 1.0) * (g.ny + 1.0));
-    k_trace_to_p1<<<corner_grid_all(), bs(), 0, stream>>>(g_all, NL, wL2, mg_b[0], dt.elen[0], dt.elen[2], dt.elen[1], partial);
-    if (mg_distributed()) {
-      vcycle_distributed_top();
-      cheb_smooth(r, z, false, nsm, mg_x[0]);
-      return false;
-    }
-    if (mg_gather) {
-      // every rank contributes its (ny+1) vertex rows; one kernel assembles the global vector from the blocks
-      const long blk = (long)(g.ny + 1) * (g.nx + 1);
-      comm->allgather(mg_b[0] + (long)g.joff * (g.nx + 1), mg_gather, (size_t)blk, stream);
-      n_gather++;
-      const long nvtx = ((long)comm->size * g.ny + 1) * (g.nx + 1);
-      k_p1_assemble<<<vec_blocks(nvtx), 256, 0, stream>>>(comm->size, g.ny, g.nx + 1, mg_gather, mg_b[0], partial);
-    }
-    run_vcycle();
+    coarse_correction(wL2);
     cheb_smooth(r, z, false, nsm, mg_x[0]);
     return false;
   }
@@ -2581,6 +2639,7 @@ struct Engine {
         n /= 2;
       }
     }
+    if (cfg.trace_precond == 1) build_dense_tail();
     psets.push_back(PSet{dt, 0.0, 0.0, cfg.tau});
     estimate_cheb(0);
     use_pset(0);
@@ -2731,36 +2790,57 @@ struct Engine {
     HIPCHECK(hipMemsetAsync(d_cgs, 0, sizeof(double) * 8, stream));
     double norm0 = -1.0;
     int its = 0;
-    // Attainable accuracy.  A solve whose right-hand side is tiny against the solution it corrects (second Richardson pass,
-    // k = 4 on 2048^2: |z0| = 2e-4) cannot reduce its residual by 1e-12: the recurrences stall a few units above the target at
-    // the rounding level of T x and p.Ap eventually turns non-positive.  A Krylov solver of the reference would sit there
-    // until its iteration limit and carry on; here a residual within three decades of the target that has not improved AT ALL
-    // for five iterations (or a breakdown at that level) ends the solve as converged to the attainable accuracy.  (A slowly but
-    // steadily converging solve -- the one-level preconditioner on a fine general mesh: 0.9 per iteration -- is not affected.)
-    double best = 1e300, last = 1e300;
-    int since_best = 0;
+    // Residual replacement (round 4; replaces the "attainable accuracy" exit of round 3, which accepted a stalled
+    // RECURRENCE residual within 1e3 rtol without looking at the true one).  A solve whose right-hand side is tiny against the
+    // iterate it corrects (second Richardson pass, k = 4 on 2048^2: |z0| = 2e-4 against an O(1) trace) cannot always reduce the
+    // recurrence residual by 1e-12: the single-reduction recurrences (s = w + beta s, p.Ap from inner products) drift from
+    // the true residual, the norm stalls a few units above the target and p.Ap eventually turns non-positive.  On either
+    // symptom -- no new best |z| for five iterations within three decades of the target, or p.Ap <= 0 -- the TRUE residual
+    // r = b - T x is recomputed, the recurrences restart from it (beta = 0), and the solve ends only if the true
+    // preconditioned residual meets rtol (hdg_imex.py:136-137) or lies at its rounding floor:
+    //     |M r| <= cg_floor_c * eps * |x|
+    // (r = b - T x cannot be evaluated more accurately than eps |T| |x| per entry, a sum of 3 n_lambda * 5 <= 75 products;
+    // M T has its spectrum in (0, 1.1], so |M delta_r| ~ sqrt(75) eps |x| ~ 10 eps |x|; cg_floor_c = 32 leaves a factor
+    // three; HDG_CG_FLOOR_C overrides).  |z| of a preconditioned CG is not monotone, so a slow but healthy solve (the one-level
+    // edge block-Jacobi preconditioner: ~0.9 per iteration) can show five non-improving iterations as well: if the true
+    // residual then agrees with the recurrence one (within a factor 4) it was a false alarm -- the restart is harmless, the
+    // patience doubles (5, 10, 20, ... iterations) and the event does not count against the limit.  At most two CONFIRMED
+    // drifts per solve; a third is HDG_ERR_NOT_CONVERGED (never silent).  Every replacement and every floor
+    // exit is counted (hdg_get_solver_events, bench line).
+    double best = 1e300, trigger_nrm = 0.0;
+    int since_best = 0, replaced = 0, drifts = 0, patience = 5;
+    bool trigger_breakdown = false;
+    bool restart = true, true_residual = true;  // the first pass starts from r = b - T x as well
+    static const double floor_c = std::getenv("HDG_CG_FLOOR_C") ? std::atof(std::getenv("HDG_CG_FLOOR_C")) : 32.0;
+    auto replace_residual = [&](const char* why, double at, bool is_breakdown) {
+      if (drifts >= 2) throw NotConverged{std::string("trace CG: ") + why + " after two residual replacements that confirmed a drifted recurrence"};
+      replaced++;
+      trigger_nrm = at; trigger_breakdown = is_breakdown;
+      ev_cg_replacements++;
+      if (debug_cg()) fprintf(stderr, "[cg] it %d: %s at |z|/|z0| %.3e: residual replacement %d\n", its, why, at / norm0, replaced);
+      HIPCHECK(hipMemsetAsync(d_cgs + 6, 0, sizeof(double), stream));
+      trace_apply(x, b, 1.0, -1.0, cg_r);  // the true residual of the current iterate
+      restart = true; true_residual = true;
+      best = 1e300; since_best = 0;
+    };
     while (true) {
       bool have_dots = false;
       if (!trace_precond(cg_r, cg_z, cg_Ap, &have_dots)) trace_apply(cg_z, nullptr, 0.0, 1.0, cg_Ap);  // w = T z
       if (!have_dots) multidot(NLv, cg_z, {tr_one, cg_r, cg_z, cg_Ap}, nullptr, KL, true);  // (z,n), (z,r), (z,z), (z,w), (n,r) -> d_res
       tally(LC_OTHER, 0.0);
       tally(LC_VEC, bL() * 11);  // k_cg_sr_update: reads z, n, w, p, s, x, r; writes p, s, x, r
-      k_cg_sr_scalars<<<1, 1, 0, stream>>>(d_res, d_cgs, tr_one_nn, its == 0 ? 1 : 0, direct_host() ? h_cgs : nullptr);  // + snapshot in pinned memory
+      k_cg_sr_scalars<<<1, 1, 0, stream>>>(d_res, d_cgs, tr_one_nn, restart ? 1 : 0, direct_host() ? h_cgs : nullptr);  // + snapshot in pinned memory
       if (!direct_host()) HIPCHECK(hipMemcpyAsync(h_cgs, d_cgs, sizeof(double) * 8, hipMemcpyDeviceToHost, stream));
       HIPCHECK(hipEventRecord(cg_ev, stream));
       k_cg_sr_update<<<nvb, 256, 0, stream>>>(NLv, d_cgs, cg_z, tr_one, cg_Ap, cg_p, cg_s, x, cg_r);
-      fl.set(cg_s, its == 0 ? fl.get(cg_Ap) : std::min(fl.get(cg_s), fl.get(cg_Ap)));
+      fl.set(cg_s, restart ? fl.get(cg_Ap) : std::min(fl.get(cg_s), fl.get(cg_Ap)));
       fl.set(cg_r, std::min(fl.get(cg_r), fl.get(cg_s)));
       fl.set(x, 0);
+      const bool was_true = true_residual;
+      restart = false; true_residual = false;
       // snapshot of iteration `its` (cg_z is intact: the next preconditioner application has not been queued)
       HIPCHECK(hipEventSynchronize(cg_ev));
-      if (h_cgs[6] == 1.0) {  // alpha was set to 0: the update just queued leaves x alone
-        if (its > 0 && last <= 1e3 * rtol * norm0) {
-          if (debug_cg()) fprintf(stderr, "[cg] it %d: p.Ap <= 0 at |z|/|z0| %.3e: attainable accuracy, accepted\n", its, last / norm0);
-          return its;
-        }
-        throw NotConverged{"trace CG: breakdown (p.Ap <= 0)"};
-      }
+      const bool breakdown = h_cgs[6] == 1.0;  // alpha was set to 0: the update just queued leaves x alone
       double zz = h_cgs[4];
       if (h_cgs[6] == 2.0) {  // z almost parallel to the null vector: measure the projected norm explicitly
         axpby(NLv, -h_cgs[3], tr_one, 1.0, cg_z);
@@ -2771,14 +2851,24 @@ struct Engine {
       if (!(zz == zz)) throw NotConverged{"trace CG: NaN residual"};
       const double nrm = std::sqrt(std::max(zz, 0.0));
       if (its == 0) { norm0 = nrm; if (norm0 == 0.0) return 0; }
-      if (debug_cg()) fprintf(stderr, "[cg] it %d |z|/|z0| %.3e  c %.3e rz %.3e\n", its, nrm / norm0, h_cgs[3], h_cgs[0]);
+      if (debug_cg()) fprintf(stderr, "[cg] it %d |z|/|z0| %.3e  c %.3e rz %.3e%s\n", its, nrm / norm0, h_cgs[3], h_cgs[0], was_true ? "  (true residual)" : "");
       if (its > 0 && nrm <= rtol * norm0) return its;
       if (cg_floor > 0.0 && nrm <= cg_floor) return its;  // backward-error stop (experiment, see pressure_solve)
-      last = nrm;
-      if (nrm < best) { best = nrm; since_best = 0; } else since_best++;
-      if (its > 0 && since_best >= 5 && nrm <= 1e3 * rtol * norm0) {
-        if (debug_cg()) fprintf(stderr, "[cg] it %d: stalled at |z|/|z0| %.3e: attainable accuracy, accepted\n", its, nrm / norm0);
-        return its;
+      if (was_true && replaced > 0) {
+        // the true preconditioned residual after a replacement: at its rounding floor?
+        const double xn = std::sqrt(std::max(dot(NLv, x, x, KL), 0.0));
+        if (debug_cg()) fprintf(stderr, "[cg] it %d: true |z| %.3e, floor %.3e (|x| %.3e)\n", its, nrm, floor_c * 2.220446049250313e-16 * xn, xn);
+        if (nrm <= floor_c * 2.220446049250313e-16 * xn) { ev_cg_floor_exits++; return its; }
+        if (trigger_breakdown || nrm > 4.0 * trigger_nrm) drifts++;  // the recurrence residual had left the true one
+        else patience *= 2;                                            // false alarm: a slow, non-monotone but healthy solve
+      }
+      if (breakdown) {
+        if (was_true) throw NotConverged{"trace CG: breakdown (p.Ap <= 0) on a freshly computed residual"};
+        replace_residual("p.Ap <= 0", nrm, true);
+      } else {
+        if (nrm < best) { best = nrm; since_best = 0; } else since_best++;
+        const bool forced = cg_force_replace > 0 && its == cg_force_replace && replaced == 0;  // test hook
+        if (forced || (its > 0 && since_best >= patience && nrm <= 1e3 * rtol * norm0)) replace_residual(forced ? "forced (test hook)" : "stall", nrm, false);
       }
       if (its >= maxit) {
         if (strict) throw NotConverged{"trace CG reached max iterations"};
@@ -2787,6 +2877,9 @@ struct Engine {
       its++;
     }
   }
+  // residual replacements / floor exits of the condensed solves since the last reset (hdg_get_solver_events)
+  long ev_cg_replacements = 0, ev_cg_floor_exits = 0;
+  int cg_force_replace = std::getenv("HDG_CG_FORCE_REPLACE") ? std::atoi(std::getenv("HDG_CG_FORCE_REPLACE")) : 0;  // test hook, read per engine
   int trace_cg(double* b, double* x, double rtol = -1.0, int maxit = -1, bool strict = true) {
     if (rtol < 0) rtol = cfg.trace_rtol;
     if (maxit < 0) maxit = cfg.trace_maxit;
@@ -3827,6 +3920,21 @@ int hdg_get_iteration_stats(hdg_handle* h, double* sums, long* counts, int reset
     if (counts) counts[i] = E.it_cnt[i];
     if (reset) { E.it_sum[i] = 0; E.it_cnt[i] = 0; }
   }
+  HDG_API_END(h)
+}
+int hdg_get_solver_events(hdg_handle* h, long* events, int reset) {
+  HDG_API_BEGIN(h)
+  if (events) { events[0] = E.ev_cg_replacements; events[1] = E.ev_cg_floor_exits; events[2] = 0; events[3] = 0; }
+  if (reset) { E.ev_cg_replacements = 0; E.ev_cg_floor_exits = 0; }
+  HDG_API_END(h)
+}
+int hdg_get_kernel_forms(hdg_handle* h, int* forms) {
+  HDG_API_BEGIN(h)
+  if (!forms) throw std::string("forms is NULL");
+  forms[0] = E.general ? 3 : (E.use_mfma_lift() ? 2 : (E.lift_pair() ? 1 : 0));
+  forms[1] = E.general ? 3 : ((E.cfg.degree >= hdg::Engine::mfma_min_degree() && !E.periodic && !std::getenv("HDG_NO_MFMA_ADV")) ? 2 : 0);
+  forms[2] = E.general ? 3 : (E.use_trace_tile() ? 1 : 0);
+  forms[3] = E.general ? 3 : (E.use_mfma_schur() ? 2 : 0);
   HDG_API_END(h)
 }
 int hdg_get_timers(hdg_handle* h, double* total_ms, double* sumsq_ms, long* ncalls, int reset) {

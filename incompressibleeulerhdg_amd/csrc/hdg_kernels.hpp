@@ -24,7 +24,7 @@ namespace hdg {
 
 struct Geo {
   // Strip partition: a rank owns the cell rows joff .. joff+ny-1 of the global
-  // nx x nyg mesh.  Every array carries GH = 4 GHOST rows below (j = -4 .. -1) and above (j = ny .. ny+3):
+  // nx x nyg mesh.  Every array carries GH = 6 GHOST rows below (j = -6 .. -1) and above (j = ny .. ny+5):
   //   cell index   c = (s*R + (j+GH))*nx + i              j in [-GH, ny+GH-1];  R >= ny+2GH rows per shape plane
   //   trace offset o = (j+GH)*P + i                        corner rows j in [-GH, ny+GH-1]
   // Depth 1 serves one row stencil.  The solvers chain stencils: a Chebyshev / GMRES iteration of the tentative
@@ -67,7 +67,9 @@ struct Geo {
   int wskip, wgap0, wgapn, wrows, wrowsc;
 };
 __device__ __forceinline__ int launch_row(const Geo& g, int r) { return r - g.elo + g.wskip + ((g.wgapn && r >= g.wgap0) ? g.wgapn : 0); }
-constexpr int GH = 4;  // ghost rows on either side of the strip in every cell / pressure / trace array
+constexpr int GH = 6;  // ghost rows on either side of the strip in every cell / pressure / trace array (round 4: 4 -> 6, so that
+                       // the LDS-tiled trace preconditioner runs on a strip with ONE exchange of r, 5 rows deep, per CG iteration)
+constexpr int DX_DEFAULT = 4;  // depth of the velocity / trace exchanges of the row-stencil solvers (Engine::Flow)
 __device__ __forceinline__ long rowbase(const Geo& g, int s, int j) { return ((long)s * g.R + (j + GH)) * g.nx; }
 __device__ __forceinline__ int xm1(const Geo& g, int i) { return i > 0 ? i - 1 : g.nx - 1; }       // column to the left
 __device__ __forceinline__ int xp1(const Geo& g, int i) { return (g.px && i == g.nx - 1) ? 0 : i + 1; }  // column to the right
@@ -2686,6 +2688,30 @@ __global__ __launch_bounds__(1024) void k_p1_vcycle_tail(P1Tail tl, const double
   for (int p = threadIdx.x; p < offs[1]; p += blockDim.x) x_out[p] = X[p];
 }
 
+// Dense form of the tail (round 4).  The tail is a fixed LINEAR map of its right-hand side (zero start, fixed sweeps), so
+// it is one matrix M of (n+1)^2 <= 1089 rows: k_p1_vcycle_tail walks through ~48 barrier-separated phases in ONE workgroup
+// (33.7 us at every mesh size, a quarter of a V-cycle at C3); M b is 9.5 MB of matrix from the L2 / Infinity Cache spread
+// over 273 workgroups.  M is built once per engine by applying the tail kernel to the unit vectors (the same operator up
+// to the rounding of the summation order); one wave per row, 16-byte loads, deterministic wave reduction.
+__global__ __launch_bounds__(256) void k_p1_dense_tail(int N, int pitch, const double* __restrict__ M, const double* __restrict__ b,
+                                                       double* __restrict__ x) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= N) return;
+  const double* __restrict__ mr = M + (long)row * pitch;
+  double acc0 = 0.0, acc1 = 0.0;
+  for (int c = 2 * lane; c < N; c += 128) {
+    const hdg_d2 m = *reinterpret_cast<const hdg_d2*>(mr + c);
+    acc0 = fma(m.x, b[c], acc0);
+    if (c + 1 < N) acc1 = fma(m.y, b[c + 1], acc1);
+  }
+  const double acc = wave_sum(acc0 + acc1);
+  if (lane == 0) x[row] = acc;
+}
+__global__ void k_transpose_sq(int N, int pitch, const double* __restrict__ in, double* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+  if (c < N) out[(long)r * pitch + c] = in[(long)c * pitch + r];
+}
+
 // trace <-> P1 transfer: P = edge-wise L2 projection of the P1 function (hdg_imex.py:491-503,
 // without the reference's 1/2 on interior edges - a preconditioner detail)
 __global__ void k_p1_to_trace(Geo g, int NL, const double* __restrict__ xc, double* __restrict__ l, double accumulate,
@@ -2857,7 +2883,6 @@ __global__ void k_trace_to_p1p(Geo g, int NL, const double* __restrict__ l, doub
 // 1..ny owned, ny+1 ghost above)
 __global__ void k_wrap_rows(double* __restrict__ v, long plane_stride, int row_len, int nplanes, int ny, int gh) {
   // array rows: gh ghost rows, ny owned rows (gh .. gh+ny-1), gh ghost rows; every ghost depth is filled
-  // (ny >= gh is checked by the engine)
   const long n = (long)nplanes * row_len * gh;
   const long stride = (long)gridDim.x * blockDim.x;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += stride) {
@@ -2865,8 +2890,10 @@ __global__ void k_wrap_rows(double* __restrict__ v, long plane_stride, int row_l
     const int rem = (int)(idx - pl * row_len * gh);
     const int d = rem / row_len, i = rem - d * row_len;
     double* p = v + pl * plane_stride;
-    p[(long)d * row_len + i] = p[(long)(ny + d) * row_len + i];                  // below <- the top gh owned rows
-    p[(long)(gh + ny + d) * row_len + i] = p[(long)(gh + d) * row_len + i];      // above <- the bottom gh owned rows
+    // ghost row j = d - gh below / j = ny + d above <- owned row j mod ny (ny may be smaller than gh: GH = 6 since round 4)
+    const int jb = ((d - gh) % ny + ny) % ny, ja = d % ny;
+    p[(long)d * row_len + i] = p[(long)(gh + jb) * row_len + i];
+    p[(long)(gh + ny + d) * row_len + i] = p[(long)(gh + ja) * row_len + i];
   }
 }
 

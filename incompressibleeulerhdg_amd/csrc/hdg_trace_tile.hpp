@@ -17,8 +17,12 @@
 // thread keeps the same corners through all stages (the index map of the halo-2 region; stages that act on a smaller region
 // mask the rest).
 //
-// Single rank, non-periodic meshes (physical boundaries only: a corner outside the mesh is a zero).  Same arithmetic per
-// corner as trace_stencil / k_trace_smooth.
+// Non-periodic meshes.  Same arithmetic per corner as trace_stencil / k_trace_smooth.  Round 4: strips as well.  A launch
+// COMPUTES the corner rows [jlo, jhi) of the rank's strip (local numbering, ghost rows included) and READS the rows
+// [rlo, rhi) = the computed rows +- the kernel's halo; a corner outside that window or outside the GLOBAL mesh is a zero
+// (it lies beyond the dependency cone of every computed row).  One rank: jlo = 0, jhi = ny + 1, the window is the mesh.
+// On a strip the pre kernel computes 3 ghost rows towards every neighbour (z valid where the post kernel's halo reads it),
+// so r has to be valid 5 ghost rows deep: ONE exchange per CG iteration (Geo: GH = 6).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -92,14 +96,19 @@ struct CornerInfo {
   int vH, vV;  // block-Jacobi variants of the corner's H and V edge
   long o;      // offset of the corner inside a trace plane
 };
-__device__ __forceinline__ CornerInfo corner_info(const Geo& g, int i, int j) {
+// rows of a tile launch: computed [jlo, jhi), readable [rlo, rhi) (local corner rows of the strip)
+struct TileRows {
+  int jlo, jhi, rlo, rhi;
+};
+__device__ __forceinline__ CornerInfo corner_info(const Geo& g, const TileRows& tr, int i, int j) {
   CornerInfo c;
-  c.exists = i >= 0 && i <= g.nx && j >= 0 && j <= g.ny;
+  const int gj = g.joff + j;  // global corner row
+  c.exists = i >= 0 && i <= g.nx && gj >= 0 && gj <= g.nyg && j >= tr.rlo && j < tr.rhi;
   c.in_x = c.exists && i < g.nx;
-  c.in_y = c.exists && j < g.ny;
-  c.below = j > 0;
+  c.in_y = c.exists && gj < g.nyg;
+  c.below = gj > 0;
   c.left = i > 0;
-  c.vH = j == 0 ? 1 : (j == g.ny ? 2 : 0);
+  c.vH = gj == 0 ? 1 : (gj == g.nyg ? 2 : 0);
   c.vV = i == 0 ? 1 : (i == g.nx ? 2 : 0);
   c.o = (long)(j + GH) * g.P + i;
   return c;
@@ -150,14 +159,14 @@ template <int NL>
 __device__ __forceinline__ int plane_of(int q) { return q < NL ? q : (q < 2 * NL ? 2 * NL + (q - NL) : NL + (q - 2 * NL)); }
 
 template <int K>
-__global__ __launch_bounds__(TraceTile<K>::NTHREADS) void k_trace_pre_tile(int ntx, int nty, Geo g, DevTables T, const double* __restrict__ r, double c0, double c1,
+__global__ __launch_bounds__(TraceTile<K>::NTHREADS) void k_trace_pre_tile(int ntx, int nty, Geo g, TileRows tr, DevTables T, const double* __restrict__ r, double c0, double c1,
                                                          double c2, double* __restrict__ z_out, double* __restrict__ res_out) {
   typedef TraceTile<K> TT;
   constexpr int NL = TT::NL, NT = TT::NT, TW = TT::TW, TH = TT::TH, W2 = TT::W2, H2 = TT::H2, W1 = TT::W1, H1 = TT::H1, KMAX = TT::KMAX;
   __shared__ double Ds[NT * TT::N2];  // d0 on the halo-2 region
   __shared__ double Zs[NT * TT::N1];  // z on the halo-1 region
   HDG_TILE_OF_BLOCK
-  const int i0 = tile_x * TW, j0 = tile_y * TH;
+  const int i0 = tile_x * TW, j0 = tr.jlo + tile_y * TH;
   double rr[KMAX][NT], dd[KMAX][NT];
   // stage 1: d0 = c0 Dinv r on the halo-2 region (pointwise); r and d0 of this thread's corners stay in registers
 #pragma unroll
@@ -165,7 +174,8 @@ __global__ __launch_bounds__(TraceTile<K>::NTHREADS) void k_trace_pre_tile(int n
     const int idx = threadIdx.x + k * TT::NTHREADS;
     if (idx < TT::N2) {
       const int lj = idx / W2, li = idx - lj * W2;
-      const CornerInfo c = corner_info(g, i0 - 2 + li, j0 - 2 + lj);
+      const int jc = j0 - 2 + lj;
+      const CornerInfo c = corner_info(g, tr, i0 - 2 + li, jc);
       load_corner<NL>(r, g, c, rr[k]);
       corner_dinv<NL>(T, c, c0, rr[k], dd[k]);
 #pragma unroll
@@ -180,7 +190,8 @@ __global__ __launch_bounds__(TraceTile<K>::NTHREADS) void k_trace_pre_tile(int n
     if (idx < TT::N2) {
       const int lj = idx / W2, li = idx - lj * W2;
       if (li >= 1 && li < W2 - 1 && lj >= 1 && lj < H2 - 1) {
-        const CornerInfo c = corner_info(g, i0 - 2 + li, j0 - 2 + lj);
+        const int jc = j0 - 2 + lj;
+        const CornerInfo c = corner_info(g, tr, i0 - 2 + li, jc);
         double z[NT];
 #pragma unroll
         for (int q = 0; q < NT; q++) z[q] = 0.0;
@@ -199,7 +210,7 @@ __global__ __launch_bounds__(TraceTile<K>::NTHREADS) void k_trace_pre_tile(int n
         }
 #pragma unroll
         for (int q = 0; q < NT; q++) Zs[(plane_of<NL>(q) * H1 + (lj - 1)) * W1 + (li - 1)] = z[q];
-        if (c.exists && li >= 2 && li < W2 - 2 && lj >= 2 && lj < H2 - 2) store_corner<NL>(z_out, g, c, z);
+        if (c.exists && li >= 2 && li < W2 - 2 && lj >= 2 && lj < H2 - 2 && jc < tr.jhi) store_corner<NL>(z_out, g, c, z);
       }
     }
   }
@@ -211,8 +222,9 @@ __global__ __launch_bounds__(TraceTile<K>::NTHREADS) void k_trace_pre_tile(int n
     if (idx < TT::N2) {
       const int lj = idx / W2, li = idx - lj * W2;
       if (li >= 2 && li < W2 - 2 && lj >= 2 && lj < H2 - 2) {
-        const CornerInfo c = corner_info(g, i0 - 2 + li, j0 - 2 + lj);
-        if (c.exists) {
+        const int jc = j0 - 2 + lj;
+        const CornerInfo c = corner_info(g, tr, i0 - 2 + li, jc);
+        if (c.exists && jc < tr.jhi) {
           double own[NT], y[3][NL], res[NT];
           lds_trace_stencil<K, W1, H1>(Zs, li - 1, lj - 1, c.in_x, c.in_y, c.below, c.left, T, own, y[0], y[1], y[2]);
 #pragma unroll
@@ -229,7 +241,7 @@ __global__ __launch_bounds__(TraceTile<K>::NTHREADS) void k_trace_pre_tile(int n
 }
 
 template <int K, bool DOTS>
-__global__ __launch_bounds__(TraceTile<K>::NTHREADS) __attribute__((amdgpu_waves_per_eu(TraceTile<K>::WPE_POST))) void k_trace_post_tile(int ntx, int nty, Geo g, DevTables T, const double* __restrict__ z_in, const double* __restrict__ r,
+__global__ __launch_bounds__(TraceTile<K>::NTHREADS) __attribute__((amdgpu_waves_per_eu(TraceTile<K>::WPE_POST))) void k_trace_post_tile(int ntx, int nty, Geo g, TileRows tr, DevTables T, const double* __restrict__ z_in, const double* __restrict__ r,
                                                           const double* __restrict__ xc, double sH, double sV, double sD, double c0,
                                                           double c1, double c2, double* __restrict__ z_out, double* __restrict__ w_out,
                                                           double* __restrict__ part) {
@@ -238,18 +250,19 @@ __global__ __launch_bounds__(TraceTile<K>::NTHREADS) __attribute__((amdgpu_waves
   __shared__ double Zs[NT * TT::N3];  // z0 on the halo-3 region; later z2 on its halo-1 part
   __shared__ double Ds[NT * TT::N2];  // d0 on the halo-2 region
   HDG_TILE_OF_BLOCK
-  const int i0 = tile_x * TW, j0 = tile_y * TH;
+  const int i0 = tile_x * TW, j0 = tr.jlo + tile_y * TH;
   const int st = g.nx + 1;
   // stage 0: z0 = z + P xc on the halo-3 region (pointwise; zero outside the mesh)
   for (int idx = threadIdx.x; idx < TT::N3; idx += TT::NTHREADS) {
     const int lj = idx / W3, li = idx - lj * W3;
     const int i = i0 - 3 + li, j = j0 - 3 + lj;
-    const CornerInfo c = corner_info(g, i, j);
+    const CornerInfo c = corner_info(g, tr, i, j);
     double z[NT];
     load_corner<NL>(z_in, g, c, z);
     if (c.exists) {
-      const double v00 = xc[(long)j * st + i];
-      const double v10 = c.in_x ? xc[(long)j * st + i + 1] : 0.0, v01 = c.in_y ? xc[(long)(j + 1) * st + i] : 0.0;
+      const long J = g.joff + j;  // xc is the global (replicated) vertex vector
+      const double v00 = xc[J * st + i];
+      const double v10 = c.in_x ? xc[J * st + i + 1] : 0.0, v01 = c.in_y ? xc[(J + 1) * st + i] : 0.0;
       if (c.in_x) edge_prolong(v00, v10, sH, z);
       if (c.in_x && c.in_y) edge_prolong(v10, v01, sD, z + NL);
       if (c.in_y) edge_prolong(v00, v01, sV, z + 2 * NL);
@@ -266,7 +279,8 @@ __global__ __launch_bounds__(TraceTile<K>::NTHREADS) __attribute__((amdgpu_waves
     const int idx = threadIdx.x + k * TT::NTHREADS;
     if (idx < TT::N2) {
       const int lj = idx / W2, li = idx - lj * W2;
-      const CornerInfo c = corner_info(g, i0 - 2 + li, j0 - 2 + lj);
+      const int jc = j0 - 2 + lj;
+      const CornerInfo c = corner_info(g, tr, i0 - 2 + li, jc);
 #pragma unroll
       for (int q = 0; q < NT; q++) r0[k][q] = z1[k][q] = d0[k][q] = 0.0;
       if (c.exists) {
@@ -295,7 +309,8 @@ __global__ __launch_bounds__(TraceTile<K>::NTHREADS) __attribute__((amdgpu_waves
     if (idx < TT::N2) {
       const int lj = idx / W2, li = idx - lj * W2;
       if (li >= 1 && li < W2 - 1 && lj >= 1 && lj < H2 - 1) {
-        const CornerInfo c = corner_info(g, i0 - 2 + li, j0 - 2 + lj);
+        const int jc = j0 - 2 + lj;
+        const CornerInfo c = corner_info(g, tr, i0 - 2 + li, jc);
         double z2[NT];
 #pragma unroll
         for (int q = 0; q < NT; q++) z2[q] = 0.0;
@@ -314,7 +329,7 @@ __global__ __launch_bounds__(TraceTile<K>::NTHREADS) __attribute__((amdgpu_waves
         }
 #pragma unroll
         for (int q = 0; q < NT; q++) Zs[(plane_of<NL>(q) * H3 + (lj + 1)) * W3 + (li + 1)] = z2[q];
-        if (c.exists && li >= 2 && li < W2 - 2 && lj >= 2 && lj < H2 - 2) store_corner<NL>(z_out, g, c, z2);
+        if (c.exists && li >= 2 && li < W2 - 2 && lj >= 2 && lj < H2 - 2 && jc < tr.jhi) store_corner<NL>(z_out, g, c, z2);
       }
     }
   }
@@ -327,8 +342,9 @@ __global__ __launch_bounds__(TraceTile<K>::NTHREADS) __attribute__((amdgpu_waves
     if (idx < TT::N2) {
       const int lj = idx / W2, li = idx - lj * W2;
       if (li >= 2 && li < W2 - 2 && lj >= 2 && lj < H2 - 2) {
-        const CornerInfo c = corner_info(g, i0 - 2 + li, j0 - 2 + lj);
-        if (c.exists) {
+        const int jc = j0 - 2 + lj;
+        const CornerInfo c = corner_info(g, tr, i0 - 2 + li, jc);
+        if (c.exists && jc < tr.jhi) {
           double own[NT], y[3][NL], w[NT];
           lds_trace_stencil<K, W3, H3>(Zs, li + 1, lj + 1, c.in_x, c.in_y, c.below, c.left, T, own, y[0], y[1], y[2]);
 #pragma unroll

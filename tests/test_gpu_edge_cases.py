@@ -135,7 +135,7 @@ def test_chebyshev_with_wrong_bounds_falls_back_to_gmres(hip_lib, tmp_path):
 
 def test_fused_vcycle_kernels_are_bitwise_equal_to_the_per_level_launches(hip_lib, tmp_path):
     """The P1 V-cycle of the trace preconditioner runs its legs as fused LDS-tile kernels (k_p1_down /
-    k_p1_up, levels with n > 32) and its tail in one workgroup (k_p1_vcycle_tail).  Both are pure
+    k_p1_up, levels with n > 32) and its tail in one workgroup (k_p1_vcycle_tail; HDG_MG_NO_DENSE_TAIL).  Both are pure
     re-schedulings of the per-level launches: the whole time step must come out bit-identical with
     either switched off.  nx = 128, 96: fused levels n = 128, 64 / 96 with partial tiles at the far boundary;
     nx = 512: enough workgroups in flight that an in-place halo race between tiles shows (it did)."""
@@ -146,8 +146,8 @@ def test_fused_vcycle_kernels_are_bitwise_equal_to_the_per_level_launches(hip_li
     here = os.path.dirname(os.path.abspath(__file__))
     for nx in (128, 96, 512):
         res = {}
-        for tag, extra in (("fused", {}), ("unfused", {"HDG_MG_NO_FUSE": "1"}),
-                           ("plain", {"HDG_MG_NO_FUSE": "1", "HDG_MG_NO_TAIL": "1"})):
+        for tag, extra in (("fused", {"HDG_MG_NO_DENSE_TAIL": "1"}), ("unfused", {"HDG_MG_NO_FUSE": "1", "HDG_MG_NO_DENSE_TAIL": "1"}),
+                           ("plain", {"HDG_MG_NO_FUSE": "1", "HDG_MG_NO_TAIL": "1"}), ("dense", {})):
             out = str(tmp_path / f"{tag}{nx}.npz")
             r = subprocess.run([sys.executable, os.path.join(here, "mp_strip_worker.py"), "0", "1", "unused", "1", str(nx),
                                 "1", out], env=dict(os.environ, **extra), stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
@@ -157,6 +157,11 @@ def test_fused_vcycle_kernels_are_bitwise_equal_to_the_per_level_launches(hip_li
         for name in ("Q", "p", "lam", "its"):
             assert np.array_equal(res["fused"][name], res["unfused"][name]), (nx, name)
             assert np.array_equal(res["fused"][name], res["plain"][name]), (nx, name)
+        # round 4 (default): the tail as ONE dense matrix-vector product (k_p1_dense_tail) -- the same linear map built from the
+        # tail kernel's action on unit vectors, another summation order: equal to rounding, same iteration counts
+        for name in ("Q", "p", "lam"):
+            assert _rel(res["dense"][name], res["fused"][name]) < 1e-10, (nx, name)
+        assert np.all(np.abs(res["dense"]["its"][1:] - res["fused"]["its"][1:]) <= 0.5), nx
 
 
 def test_alternative_trace_solver_paths_agree(hip_lib, tmp_path):

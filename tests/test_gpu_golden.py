@@ -105,3 +105,26 @@ def test_operator_golden(hip_lib):
     # set_state removes the pressure mean; lambda shifts by the same constant
     shift = e.integrate_pressure(g["p"])
     assert _relerr(lam, g["lam"] - shift) < 1e-11
+
+
+def test_engine_config_holds_the_reference_tableaux(hip_lib):
+    """The hdg_config an engine is built with (what crosses the C-ABI) carries the tableau of the reference fixture
+    (tests/golden/tableaux_reference.json, extracted from hdg_imex.py:668-1038) bit for bit, for all five classes."""
+    import json
+
+    from incompressibleeulerhdg_amd import timesteppers as ts
+    from incompressibleeulerhdg_amd.mesh import UnitSquareMesh
+
+    with open(os.path.join(GOLD, "tableaux_reference.json")) as f:
+        classes = json.load(f)["classes"]
+    for cname, e in classes.items():
+        t = getattr(ts, cname)(UnitSquareMesh(4, 4), 1, 0.01)
+        cfg = t._engine.cfg
+        s = e["nstages"]
+        assert cfg.nstages == s and t.label == e["label"]
+        ref = {k: np.array([float.fromhex(h) for h in e[k]["hex"]]).reshape(e[k]["shape"]) for k in ("a_expl", "a_impl", "b_expl", "b_impl", "c_expl")}
+        assert np.array_equal(np.array(cfg.a_expl[:s * s]).reshape(s, s), ref["a_expl"])
+        assert np.array_equal(np.array(cfg.a_impl[:s * s]).reshape(s, s), ref["a_impl"])
+        assert np.array_equal(np.array(cfg.b_expl[:s]), ref["b_expl"]) and np.array_equal(np.array(cfg.c_expl[:s]), ref["c_expl"])
+        nb = len(ref["b_impl"])  # ARS3(4,4,3): 6 entries as written (the first 5 are read)
+        assert np.array_equal(np.array(cfg.b_impl[:nb]), ref["b_impl"])

@@ -135,6 +135,11 @@ def test_ghost_row_bookkeeping_self_check(hip_lib, tmp_path, nranks, k, nx, opts
     # the exchanges that were NOT skipped ran beside an interior launch (interior / boundary split on a second stream)
     m2 = re.search(r"\((\d+) of them beside an interior launch\)", logs[0])
     assert m2 and int(m2.group(1)) > 10, logs[0][-2000:]
+    # round 4: strips of >= 5 rows run the LDS-tiled trace preconditioner of the one-GPU path (k <= 3; one exchange of r, 5 rows
+    # deep, per CG iteration); shorter strips and k = 4 keep the row-stencil kernels
+    m3 = re.search(r"tiled trace preconditioner applications (\d+)", logs[0])
+    assert m3, logs[0][-2000:]
+    assert (int(m3.group(1)) > 20) == (k <= 3 and nx // nranks >= 5), (m3.group(0), k, nx, nranks)
 
 
 def test_strip_partition_at_the_benchmark_size(hip_lib, tmp_path):
@@ -160,7 +165,10 @@ def test_strip_partition_at_the_benchmark_size(hip_lib, tmp_path):
     s1, c1 = ts._engine.iteration_stats()
     assert np.all(np.abs(parts[0]["its"][1:] - (s1 / np.maximum(c1, 1))[1:]) <= 1.0)
     m = re.search(r"\[flow check\] (\d+) skipped exchanges verified, worst relative deviation ([0-9.eE+-]+)", logs[0])
-    assert m and int(m.group(1)) > 100 and float(m.group(2)) < 1e-12, logs[0][-1500:]
+    # (round 3: > 100 per step with the row-stencil preconditioner; the tiled one exchanges r once per CG iteration and skips none)
+    assert m and int(m.group(1)) > 50 and float(m.group(2)) < 1e-12, logs[0][-1500:]
+    m3 = re.search(r"tiled trace preconditioner applications (\d+)", logs[0])
+    assert m3 and int(m3.group(1)) >= 60, logs[0][-1500:]  # the strips run the one-GPU path's tile kernels
 
 
 def test_strip_partition_unsplit(hip_lib, tmp_path):
