@@ -97,31 +97,30 @@ FP64_MATRIX_PEAK_TF = 78.6  # MI355X FP64 matrix = FP64 vector peak (AMD datashe
 
 def roofline_block(eng, args, nx, k, world, ktimers=None, timed_where="the timed steps"):
     """Roofline of the dominant kernel.  Durations of the two kernels of a tentative-velocity iteration: HIP-event
-    brackets around every launch of the timed steps (`ktimers`, hdg_set_kernel_timing; `timing: "in place"`), for
-    the other kernels a stand-alone launch loop on the engine's stream (hdg_time_kernel).
+    brackets around every launch, by FORM (`ktimers`, hdg_set_kernel_timing; `timing: "in place"`), for the other kernels a
+    stand-alone launch loop on the engine's stream (hdg_time_kernel).
 
     An iteration of the tentative-velocity solve (55-60 % of the step) is two launches: the advection operator and
     the hybrid preconditioner (BDM lift with the element block-Jacobi folded into the lifting tables).  The forms of a
     kernel are separate instantiations with their own names (last template argument), so profiles tell them apart:
-      Chebyshev phase (default):  k_adv_apply<K, true> / k_adv_mfma<K, true>: residual form t = b - (I - gamma F(Q*)) x
+      Chebyshev phase:            k_adv_apply<K, true> / k_adv_mfma<K, true>: residual form t = b - (I - gamma F(Q*)) x
                                   (reads x, Q*, b, writes t: 4 vectors of 8 N_Q bytes, SURVEY.md section 8d);
-                                  k <= 2: k_edge_lift_pair<K, false, 2, true> (nx <= 64: k_edge_lift<...>) with the fused Chebyshev step (reads t, x_n, x_{n-1},
-                                  writes x_{n+1}: 4 vectors);  k >= 3: k_edge_lift_mfma<K, true>, the matrix-core lift with the same
-                                  fused step (4 vectors; HDG_MFMA_CHEB_UNFUSED: plain lift + separate k_cheb_update);
-      GMRES phase:                k_adv_apply<K, false> / k_adv_mfma<K, false> (reads x, Q*, writes y: 3 vectors) and the plain
-                                  lift (2 vectors).
-    k <= 2: bound HBM.  k >= 3: bound FP64 MFMA; `achieved` counts the ALGORITHMIC flops (unpadded contraction shapes),
-    `mfma_util` the issued v_mfma_f64_16x16x4 (padding included).  Whichever of the two takes longer per launch is the
-    dominant kernel.  The brackets (hdg_set_kernel_timing) time the form the configured solver iterates with."""
+                                  k <= 2: k_edge_lift_pair<K, false, 2, true> (nx <= 64: k_edge_lift<...>) with the fused Chebyshev
+                                  step (reads t, x_n, x_{n-1}, writes x_{n+1}: 4 vectors);  k >= 3: k_edge_lift_mfma<K, true>;
+      GMRES / s-step cycles:      k_adv_apply<K, false> / k_adv_mfma<K, false> (reads x, Q*, writes y: 3 vectors) and the plain
+                                  lift (2 vectors).  Since round 4 (s-step tail, early hand-over) these are the MORE frequent forms.
+    k <= 2: bound HBM.  k >= 3: the advection kernels are bound by FP64 MFMA; `achieved` counts the ALGORITHMIC flops (unpadded
+    contraction shapes), `mfma_util` the issued v_mfma_f64_16x16x4 (padding included).  The DOMINANT kernel is the form with the
+    largest total time over the bracketed step (launches x average duration); the other three are listed in `other_kernels`."""
     NQ = eng.n_cells * 2 * eng.n_u  # this rank's strip: kernel timings are per-rank launches
     NL = eng.n_edges * eng.n_l
     NP = eng.n_cells * eng.n_p
     NU = eng.n_u
     hybrid = args.tent_precond == 2
-    cheb = eng.cfg.tent_solver == 1
     forms = eng.kernel_forms()
     mfma = forms["advection"] == 2 and forms["lift"] == 2
     gbs = lambda b, ms: b / (ms * 1e-3) / 1e9
+    tf = lambda fl, ms: fl / (ms * 1e-3) / 1e12
     ms_triad = eng.time_kernel(8, 20)  # y = a x + b y on velocity vectors: the HBM rate this box delivers
     triad = gbs(8.0 * 3 * NQ, ms_triad)
     others = {}
@@ -136,75 +135,72 @@ def roofline_block(eng, args, nx, k, world, ktimers=None, timed_where="the timed
         if tj.get("csrc_sha16") == csrc_sha16() and world == 1:
             for cfg in tj["configs"].values():
                 if cfg["workload"] == {"nx": nx, "degree": k}:
-                    kn = cfg["kernels"]
-                    fm = "true" if cheb else "false"
-                    lk = lift_kernel_name(eng)
-                    for key, names in (("adv", (f"k_adv_apply<{k}, {fm}>", f"k_adv_mfma<{k}, {fm}>")),
-                                       ("lift", (f"{lk}<{k}, false, 2, {fm}>", f"k_edge_lift_mfma<{k}, {fm}>"))):
-                        for nm in names:
-                            if nm in kn and (k <= 2) == ("mfma" not in nm):
-                                pmc[key] = kn[nm]["hbm_bytes"]
-                            if nm in cfg.get("mfma", {}):
-                                pmc_mfma[key] = cfg["mfma"][nm]["mfma_busy_frac"]
+                    pmc = {nm: v["hbm_bytes"] for nm, v in cfg["kernels"].items()}
+                    pmc_mfma = {nm: v["mfma_busy_frac"] for nm, v in cfg.get("mfma", {}).items()}
     except Exception:
         pmc, pmc_mfma = {}, {}
-    if not mfma:
-        kid_lift = (6 if hybrid else 4) if cheb else (9 if hybrid else 4)
-        ms_lift_alone = eng.time_kernel(kid_lift, 20)
-        ms_adv_alone = eng.time_kernel(7 if cheb else 0, 20)
-        in_place = lambda lab, alone: (ktimers[lab][1] / ktimers[lab][0] * 1e3, ktimers[lab][0]) if ktimers and ktimers.get(lab, (0, 0))[0] else (alone, 0)
-        (ms_lift, n_lift), (ms_adv, n_adv) = in_place("kernel_lift", ms_lift_alone), in_place("kernel_advection", ms_adv_alone)
-        nv_lift = ((4 if hybrid else 6) if cheb else 2)
-        nv_adv = 4 if cheb else 3
-        lift_name = (f"{lift_kernel_name(eng) if hybrid else 'k_edge_lift'}<{k}, false, {2 if hybrid else 1}, {'true' if cheb else 'false'}>"
-                     + (" (lift + fused Chebyshev step)" if cheb else ""))
-        adv_name = f"k_adv_apply<{k}, {'true' if cheb else 'false'}>" + (" (residual form b - (I - gamma F) x)" if cheb else "")
-        cand = {"lift": (lift_name, 8.0 * nv_lift * NQ, ms_lift), "adv": (adv_name, 8.0 * nv_adv * NQ, ms_adv)}
-        dom = "adv" if ms_adv >= ms_lift else "lift"
-        oth = "lift" if dom == "adv" else "adv"
-        dname, dbytes, dms = cand[dom]
-        alone = {"lift": ms_lift_alone, "adv": ms_adv_alone}
-        nl = {"lift": n_lift, "adv": n_adv}
-        others[cand[oth][0]] = dict(ms=cand[oth][2], GBs=gbs(cand[oth][1], cand[oth][2]), algorithmic_bytes=cand[oth][1],
-                                    traffic=pmc.get(oth), launches_timed=nl[oth], ms_stand_alone=alone[oth])
-        return dict(bound="hbm", kernel=dname, achieved=gbs(dbytes, dms), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=gbs(dbytes, dms) / HBM_PEAK_GBS, traffic=pmc.get(dom), algorithmic_bytes=dbytes, ms_per_launch=dms,
-                    timing=("in place: HIP-event pair around each launch of " + timed_where) if nl[dom] else "stand-alone launch loop",
-                    launches_timed=nl[dom], ms_stand_alone=alone[dom],
-                    stream_triad_GBs=triad, frac_of_triad=gbs(dbytes, dms) / triad, other_kernels=others)
-    # matrix-core kernels (k >= 3)
-    nq = {3: 36, 4: 64}[k]
-    nqe = (3 * k + 5) // 2
-    ksu, mtu, mtq = (NU + 3) // 4, (NU + 15) // 16, (nq + 15) // 16
-    n2 = 2 * NU
-    ks, mt = (n2 + 3) // 4, (n2 + 15) // 16
-    tiles = eng.n_cells / 16.0  # one wave trip per 16 cells (partial tiles of a row ignored)
-    adv_issued = (mtq * (6 * ksu + 8 * mtu) + 8 * ksu + 6 * ksu + 12 * mtu) * 2048.0 * tiles
-    adv_alg = eng.n_cells * (nq * (16.0 * NU + 8) + 3 * nqe * (14.0 * NU + 20))
-    ne = k + 2
-    lift_issued = (5 * ks + 5 * mt) * 2048.0 * tiles
-    lift_alg = eng.n_cells * (2.0 * 3 * ne * n2 * 2 + 2.0 * n2 * 3 * ne)  # own + neighbour moments, lifting
-    ms_adv_alone = eng.time_kernel(7 if cheb else 0, 20)
-    ms_lift_alone = eng.time_kernel(9, 20)
-    in_place = lambda lab, alone: (ktimers[lab][1] / ktimers[lab][0] * 1e3, ktimers[lab][0]) if ktimers and ktimers.get(lab, (0, 0))[0] else (alone, 0)
-    (ms_lift, n_lift), (ms_adv, n_adv) = in_place("kernel_lift", ms_lift_alone), in_place("kernel_advection", ms_adv_alone)
-    tf = lambda fl, ms: fl / (ms * 1e-3) / 1e12
-    # in place: the form the solver iterates with (Chebyshev phase: fused step, 4 vectors); stand-alone loop: the plain lift
-    fused = cheb and n_lift > 0 and not os.environ.get("HDG_MFMA_CHEB_UNFUSED")
-    nv_lift = 4 if fused else 2
-    lift_label = f"k_edge_lift_mfma<{k}, {'true' if fused else 'false'}>" + (" (lift + fused Chebyshev step)" if fused else "")
-    others[lift_label] = dict(ms=ms_lift, TFLOPs=tf(lift_alg, ms_lift), mfma_util=tf(lift_issued, ms_lift) / FP64_MATRIX_PEAK_TF,
-                                             GBs=gbs(8.0 * nv_lift * NQ, ms_lift), algorithmic_bytes=8.0 * nv_lift * NQ, traffic=pmc.get("lift"),
-                                             mfma_busy_pmc=pmc_mfma.get("lift"), launches_timed=n_lift, ms_stand_alone=ms_lift_alone)
-    nv_adv = 4 if cheb else 3  # residual form reads b as well
-    return dict(bound="mfma", kernel=f"k_adv_mfma<{k}, {'true' if cheb else 'false'}>" + (" (residual form)" if cheb else ""),
-                achieved=tf(adv_alg, ms_adv), peak=FP64_MATRIX_PEAK_TF, unit="TFLOP/s",
-                frac=tf(adv_alg, ms_adv) / FP64_MATRIX_PEAK_TF, mfma_util=tf(adv_issued, ms_adv) / FP64_MATRIX_PEAK_TF,
-                mfma_busy_pmc=pmc_mfma.get("adv"),  # SQ_VALU_MFMA_BUSY_CYCLES / (kernel cycles x 1024 SIMDs), profiles/pmc_traffic.json
-                algorithmic_flops=adv_alg, issued_mfma_flops=adv_issued, ms_per_launch=ms_adv, traffic=pmc.get("adv"),
-                timing=("in place: HIP-event pair around each launch of " + timed_where) if n_adv else "stand-alone launch loop",
-                launches_timed=n_adv, ms_stand_alone=ms_adv_alone,
-                hbm_GBs=gbs(8.0 * nv_adv * NQ, ms_adv), algorithmic_bytes=8.0 * nv_adv * NQ, stream_triad_GBs=triad, other_kernels=others)
+    lk = lift_kernel_name(eng)
+    if mfma:
+        nq = {3: 36, 4: 64}[k]
+        nqe = (3 * k + 5) // 2
+        ksu, mtu, mtq = (NU + 3) // 4, (NU + 15) // 16, (nq + 15) // 16
+        n2 = 2 * NU
+        ks, mt = (n2 + 3) // 4, (n2 + 15) // 16
+        tiles = eng.n_cells / 16.0  # one wave trip per 16 cells (partial tiles of a row ignored)
+        adv_issued = (mtq * (6 * ksu + 8 * mtu) + 8 * ksu + 6 * ksu + 12 * mtu) * 2048.0 * tiles
+        adv_alg = eng.n_cells * (nq * (16.0 * NU + 8) + 3 * nqe * (14.0 * NU + 20))
+        ne = k + 2
+        lift_issued = (5 * ks + 5 * mt) * 2048.0 * tiles
+        lift_alg = eng.n_cells * (2.0 * 3 * ne * n2 * 2 + 2.0 * n2 * 3 * ne)  # own + neighbour moments, lifting
+        cands = {
+            "kernel_advection": (f"k_adv_mfma<{k}, true>", " (residual form b - (I - gamma F) x)", 8.0 * 4 * NQ, 7, adv_alg, adv_issued),
+            "kernel_lift": (f"k_edge_lift_mfma<{k}, true>", " (lift + fused Chebyshev step)", 8.0 * 4 * NQ, 6, lift_alg, lift_issued),
+            "kernel_advection_plain": (f"k_adv_mfma<{k}, false>", " (plain operator)", 8.0 * 3 * NQ, 0, adv_alg, adv_issued),
+            "kernel_lift_plain": (f"k_edge_lift_mfma<{k}, false>", " (plain hybrid lift)", 8.0 * 2 * NQ, 9, lift_alg, lift_issued),
+        }
+    else:
+        lt = f"{lk if hybrid else 'k_edge_lift'}<{k}, false, {2 if hybrid else 1}"
+        cands = {
+            "kernel_advection": (f"k_adv_apply<{k}, true>", " (residual form b - (I - gamma F) x)", 8.0 * 4 * NQ, 7, None, None),
+            "kernel_lift": (f"{lt}, true>", " (lift + fused Chebyshev step)", 8.0 * (4 if hybrid else 6) * NQ, 6 if hybrid else 4, None, None),
+            "kernel_advection_plain": (f"k_adv_apply<{k}, false>", " (plain operator)", 8.0 * 3 * NQ, 0, None, None),
+            "kernel_lift_plain": (f"{lt}, false>", " (plain hybrid lift)", 8.0 * 2 * NQ, 9 if hybrid else None, None, None),
+        }
+    rows = {}
+    for lab, (name, note, nbytes, kid, alg, issued) in cands.items():
+        n, tot = (ktimers or {}).get(lab, (0, 0.0))
+        alone = eng.time_kernel(kid, 20) if kid is not None else None
+        if n:
+            ms = tot / n * 1e3
+        elif alone is not None:
+            ms = alone
+        else:
+            continue
+        row = dict(ms=ms, GBs=gbs(nbytes, ms), algorithmic_bytes=nbytes, traffic=pmc.get(name), launches_timed=n,
+                   total_ms_in_bracketed_step=n * ms, ms_stand_alone=alone)
+        if alg is not None:
+            row.update(TFLOPs=tf(alg, ms), mfma_util=tf(issued, ms) / FP64_MATRIX_PEAK_TF, mfma_busy_pmc=pmc_mfma.get(name),
+                       algorithmic_flops=alg, issued_mfma_flops=issued)
+        rows[lab] = (name + note, row)
+    # dominant: largest total time in the bracketed step; without brackets the longest launch
+    dom = max(rows, key=lambda lab: (rows[lab][1]["total_ms_in_bracketed_step"], rows[lab][1]["ms"]))
+    dname, drow = rows[dom]
+    for lab, (name, row) in rows.items():
+        if lab != dom:
+            others[name] = row
+    timing = ("in place: HIP-event pair around each launch of " + timed_where) if drow["launches_timed"] else "stand-alone launch loop"
+    if mfma and dom.startswith("kernel_advection"):
+        return dict(bound="mfma", kernel=dname, achieved=drow["TFLOPs"], peak=FP64_MATRIX_PEAK_TF, unit="TFLOP/s",
+                    frac=drow["TFLOPs"] / FP64_MATRIX_PEAK_TF, mfma_util=drow["mfma_util"], mfma_busy_pmc=drow["mfma_busy_pmc"],
+                    algorithmic_flops=drow["algorithmic_flops"], issued_mfma_flops=drow["issued_mfma_flops"], ms_per_launch=drow["ms"],
+                    traffic=drow["traffic"], timing=timing, launches_timed=drow["launches_timed"], ms_stand_alone=drow["ms_stand_alone"],
+                    total_ms_in_bracketed_step=drow["total_ms_in_bracketed_step"],
+                    hbm_GBs=drow["GBs"], algorithmic_bytes=drow["algorithmic_bytes"], stream_triad_GBs=triad, other_kernels=others)
+    return dict(bound="hbm", kernel=dname, achieved=drow["GBs"], peak=HBM_PEAK_GBS, unit="GB/s", frac=drow["GBs"] / HBM_PEAK_GBS,
+                traffic=drow["traffic"], algorithmic_bytes=drow["algorithmic_bytes"], ms_per_launch=drow["ms"], timing=timing,
+                launches_timed=drow["launches_timed"], ms_stand_alone=drow["ms_stand_alone"],
+                total_ms_in_bracketed_step=drow["total_ms_in_bracketed_step"],
+                stream_triad_GBs=triad, frac_of_triad=drow["GBs"] / triad, other_kernels=others)
 
 
 def cpu_baseline(degree, nx_sample=None):

@@ -194,13 +194,14 @@ int hdg_get_solver_events(hdg_handle* h, long* events, int reset);
  * step), so hdg_step / hdg_run_separable report the same per-solve breakdown as the per-solve calls.  For each label
  * total_ms[i], sumsq_ms[i] (sum of squares, for the standard deviation log_summary prints) and ncalls[i] since the
  * last reset. */
-#define HDG_N_TIMERS 7
+#define HDG_N_TIMERS 9
 int hdg_get_timers(hdg_handle* h, double* total_ms, double* sumsq_ms, long* ncalls, int reset);
-/* Labels 5 and 6 (no reference counterpart; the measurement SURVEY.md section 8(d) asks for): every launch of the two
- * kernels of a tentative-velocity iteration -- 5: advection operator (k <= 2: residual form b - (I - gamma F) x of the
- * Chebyshev iteration; k >= 3: the plain operator GMRES applies), 6: hybrid edge-lift preconditioner (with the fused
- * Chebyshev step / plain) -- bracketed by its own event pair IN PLACE, i.e. with the operands and cache state of the
- * solve.  Recorded only while switched on (two event records per launch: about 1 % of a C3 step). */
+/* Labels 5 .. 8 (no reference counterpart; the measurement SURVEY.md section 8(d) asks for): every launch of the two
+ * kernels of a tentative-velocity iteration inside a solver, by FORM -- 5: advection operator in residual form
+ * b - (I - gamma F) x (Chebyshev phase, first residual of a cycle), 6: hybrid edge-lift preconditioner with the fused
+ * Chebyshev step, 7: plain advection operator, 8: plain hybrid lift (7, 8: GMRES and the s-step cycles) -- bracketed by its
+ * own event pair IN PLACE, i.e. with the operands and cache state of the solve.  Recorded only while switched on (two event
+ * records per launch: about 1 % of a C3 step). */
 int hdg_set_kernel_timing(hdg_handle* h, int on);
 /* Transport of a distributed handle as the transport itself reports it: this rank, the number of ranks of the strip
  * partition, the size of the communicator (RCCL: ncclCommCount; must equal nranks) and its name ("self", "rccl", "shm";

@@ -436,12 +436,13 @@ class Engine:
         return out
 
     TIMER_LABELS = ("timestep", "bdm_projection", "tentative_velocity_solve", "pressure_solve", "unsplit_solve")
-    KERNEL_TIMER_LABELS = ("kernel_advection", "kernel_lift")  # hdg_set_kernel_timing; no reference counterpart
+    # hdg_set_kernel_timing; no reference counterpart: the two kernels of a tentative-velocity iteration by form
+    KERNEL_TIMER_LABELS = ("kernel_advection", "kernel_lift", "kernel_advection_plain", "kernel_lift_plain")
 
     def timers(self, reset=False, kernels=False):
         """Device-side section timers (labels of the reference's PerformanceLog): {label: (ncall, total_s, sumsq_s2)};
         kernels=True adds the per-launch brackets of the two kernels of a tentative-velocity iteration."""
-        n = 7
+        n = 9  # HDG_N_TIMERS
         tot, sq = np.zeros(n), np.zeros(n)
         cnt = np.zeros(n, dtype=np.int64)
         self._ck(self.lib.hdg_get_timers(self.h, _ptr(tot), _ptr(sq), cnt.ctypes.data_as(_lp), 1 if reset else 0))

@@ -147,9 +147,11 @@ struct Engine {
   // T_KADV / T_KLIFT (hdg_set_kernel_timing): every launch of the two kernels of a tentative-velocity iteration -- the
   // advection operator in residual form and the hybrid lift with its Chebyshev / GMRES epilogue -- bracketed on its own,
   // in place (same operands, same cache state as in the solve): what bench.py's roofline block divides by.
-  enum { T_STEP = 0, T_BDM = 1, T_TENT = 2, T_PRESS = 3, T_UNSPLIT = 4, T_KADV = 5, T_KLIFT = 6 };
-  double tm_total[HDG_N_TIMERS] = {0, 0, 0, 0, 0, 0, 0}, tm_sumsq[HDG_N_TIMERS] = {0, 0, 0, 0, 0, 0, 0};
-  long tm_calls[HDG_N_TIMERS] = {0, 0, 0, 0, 0, 0, 0};
+  // Round 4: one label per FORM (the s-step tail makes the plain forms the more frequent ones at k >= 2): T_KADV = residual form
+  // b - A x, T_KLIFT = lift with the fused Chebyshev step, T_KADV_PLAIN / T_KLIFT_PLAIN = the forms GMRES and the s-step cycles use.
+  enum { T_STEP = 0, T_BDM = 1, T_TENT = 2, T_PRESS = 3, T_UNSPLIT = 4, T_KADV = 5, T_KLIFT = 6, T_KADV_PLAIN = 7, T_KLIFT_PLAIN = 8 };
+  double tm_total[HDG_N_TIMERS] = {0}, tm_sumsq[HDG_N_TIMERS] = {0};
+  long tm_calls[HDG_N_TIMERS] = {0};
   struct Section { int label; hipEvent_t e0, e1; };
   std::vector<Section> tm_open;       // recorded, not yet harvested
   std::vector<hipEvent_t> tm_pool;    // idle events
@@ -1239,8 +1241,7 @@ struct Engine {
                   double* chx_ = nullptr, double c1 = 0.0, double c2 = 0.0, double* ss = nullptr) {
     // Chebyshev mode: the lift of an iteration carries the fused step (per-thread kernel) or is the matrix-core kernel
     // followed by the vector-kernel step; GMRES mode: the plain lift
-    KTimed kt_(*this, T_KLIFT, fl.active() && (cfg.tent_solver == 1 ? (chd_ != nullptr || (use_mfma_lift() && out && !ss))
-                                                                      : chd_ == nullptr));
+    KTimed kt_(*this, chd_ != nullptr ? T_KLIFT : T_KLIFT_PLAIN, fl.active() && (chd_ != nullptr || (out && !ss)));
     tally(LC_LIFT, lift_bytes(false, out != nullptr, chd_ != nullptr, c1));
     std::vector<const double*> pw;
     if (chd_) { pw.push_back(chx_); if (c1 != 0.0) pw.push_back(chd_); }
@@ -1274,7 +1275,7 @@ struct Engine {
     fl.set(out, ext);
   }
   void adv_apply(const double* x, const double* qstar, double* out, double gamma, const double* bsub = nullptr) {
-    KTimed kt_(*this, T_KADV, fl.active() && ((cfg.tent_solver == 1) == (bsub != nullptr)));
+    KTimed kt_(*this, bsub != nullptr ? T_KADV : T_KADV_PLAIN, fl.active());
     const double up = cfg.flux_upwind ? 1.0 : 0.0;
     tally(LC_ADV, bQ() * (bsub ? 4 : 3));
     if (general) {
@@ -2067,6 +2068,166 @@ struct Engine {
     return ev;
   }
 
+  // s-step minimal-residual cycles on the left-preconditioned operator B = M (I - gamma F(Q*)) (hdg_kernels.hpp: k_gram,
+  // k_sstep_update): the tail of the Chebyshev iteration (round 3: one GMRES(8) cycle, whose Gram-Schmidt passes cost more
+  // than its operator applications).  Power basis K_0 = M(b - A x), K_i = B K_{i-1}, i <= s (s <= 6: 28 inner products fit one
+  // reduction); the least-squares coefficients come from the Gram matrix by a Cholesky factorisation of its scaled trailing
+  // block in long double, truncated at the first pivot below 1e-13 (a residual that a few eigenvectors dominate -- the very
+  // situation at the hand-over -- spans a nearly invariant subspace: the basis then IS rank deficient and the truncated
+  // problem is the right one).  Whatever y is, x += sum y_i K_{i-1} and r' = K_0 - sum y_i K_i stay consistent (r' is the
+  // preconditioned residual of the new x up to rounding), so the accuracy of y decides the progress of a cycle only, never
+  // the answer; the norm of r' is measured, not predicted.  Same stopping rule as GMRES and the Chebyshev iteration:
+  // |M r| <= rtol |M r_0| (beta0).  cur0 > 0: the norm of the current preconditioned residual as the caller last measured it
+  // (the cycle length is chosen from the reduction still needed: 1.7 iterations per decade + 1, GMRES's observed 5-6 for 3-4
+  // decades).  Two cycles in a row that gain less than a factor 2 hand the solve to GMRES (which throws at its iteration limit).
+  long n_sstep_cycles = 0, n_sstep_fallbacks = 0;
+  double *d_gram = nullptr, *h_gram = nullptr;
+  // least-squares coefficients of min |K_0 - sum_{i=1..sl} y_i K_i| from the Gram matrix G ((sl+1) x (sl+1), row-major):
+  // scaled normal equations, Cholesky in long double truncated at the first pivot below 1e-13; returns the rank and the
+  // predicted residual norm (from the Gram matrix: reliable down to reductions of ~1e-6 of |K_0|)
+  static int sstep_ls(const std::vector<long double>& G, int nv, int sl, std::vector<long double>& y, double& rho) {
+    std::vector<long double> d(sl), L((size_t)sl * sl, 0.0L), rhs(sl);
+    y.assign(sl, 0.0L);
+    for (int i = 0; i < sl; i++) d[i] = std::sqrt(std::max(G[(size_t)(i + 1) * nv + (i + 1)], (long double)1e-300));
+    int rank = 0;
+    for (int j = 0; j < sl; j++) {
+      long double piv = 1.0L;
+      for (int q = 0; q < j; q++) piv -= L[(size_t)j * sl + q] * L[(size_t)j * sl + q];
+      if (!(piv > 1e-13L)) break;
+      L[(size_t)j * sl + j] = std::sqrt(piv);
+      for (int i = j + 1; i < sl; i++) {
+        long double v = G[(size_t)(i + 1) * nv + (j + 1)] / (d[i] * d[j]);
+        for (int q = 0; q < j; q++) v -= L[(size_t)i * sl + q] * L[(size_t)j * sl + q];
+        L[(size_t)i * sl + j] = v / L[(size_t)j * sl + j];
+      }
+      rank = j + 1;
+    }
+    for (int i = 0; i < rank; i++) {  // forward, then backward substitution on the leading rank x rank block
+      long double v = G[(size_t)(i + 1) * nv] / d[i];
+      for (int q = 0; q < i; q++) v -= L[(size_t)i * sl + q] * rhs[q];
+      rhs[i] = v / L[(size_t)i * sl + i];
+    }
+    for (int i = rank - 1; i >= 0; i--) {
+      long double v = rhs[i];
+      for (int q = i + 1; q < rank; q++) v -= L[(size_t)q * sl + i] * y[q];
+      y[i] = v / L[(size_t)i * sl + i];
+    }
+    for (int i = 0; i < rank; i++) y[i] /= d[i];
+    long double r2 = G[0];
+    for (int i = 0; i < rank; i++) {
+      r2 -= 2.0L * y[i] * G[(size_t)(i + 1) * nv];
+      for (int q = 0; q < rank; q++) r2 += y[i] * y[q] * G[(size_t)(i + 1) * nv + (q + 1)];
+    }
+    rho = std::sqrt((double)std::max(r2, 0.0L));
+    return rank;
+  }
+  int sstep_mr(const double* qstar, double gamma, int didx, const double* b, double* x, double rtol, double beta0, double cur0) {
+    FlowScope flow_(*this);
+    flow_fixed_Q(qstar);
+    flow_fixed_Q(b);
+    static const int smax_env = std::getenv("HDG_SSTEP_MAX") ? std::atoi(std::getenv("HDG_SSTEP_MAX")) : 6;
+    static const double per_decade = std::getenv("HDG_SSTEP_PER_DECADE") ? std::atof(std::getenv("HDG_SSTEP_PER_DECADE")) : 1.7;
+    const int smax = std::max(2, std::min(std::min(smax_env, HDG_SSTEP_MAXV - 1), (int)gm_V.size() - 1));
+    if (!d_gram) {
+      d_gram = dalloc(64);
+      HIPCHECK(hipHostMalloc((void**)&h_gram, sizeof(double) * 64));
+    }
+    double* t = wQ2;
+    const RowMask mk = mask_for(KQ);
+    const double target = rtol * beta0;
+    const bool direct = comm->size == 1 && direct_host();
+    auto length_for = [&](double from) {  // iterations for the reduction from -> target at GMRES's observed tail rate
+      return (int)std::ceil(per_decade * std::log10(std::max(from / target, 1.0)));
+    };
+    int its = 0, weak = 0;
+    double cur = cur0;
+    bool have_r = false;
+    while (true) {
+      if (!have_r) {
+        adv_apply(x, qstar, t, gamma, b);  // t = b - A x
+        tent_precond(didx, t, gm_V[0]);
+      }
+      int built = 0;
+      int want = cur > 0.0 ? std::max(2, std::min(smax, length_for(cur) + 1)) : std::min(6, smax);
+      std::vector<long double> G, yv;
+      int nv = 0, rank = 0;
+      double k0n = 0.0, rho = 0.0;
+      while (true) {
+        for (int i = built + 1; i <= want; i++) {
+          adv_apply(gm_V[i - 1], qstar, t, gamma);
+          tent_precond(didx, t, gm_V[i]);
+          its++;
+        }
+        built = want;
+        nv = built + 1;
+        const int npair = nv * (nv + 1) / 2;
+        const int nb = std::min(std::min(dot_blocks, vec_blocks(NQ)), (dot_blocks * MAXV) / npair);
+        tally(LC_DOT, bQ() * nv);
+        tally(LC_OTHER, 0.0);
+        VecList<HDG_SSTEP_MAXV> vl;
+        for (int q = 0; q < HDG_SSTEP_MAXV; q++) vl.p[q] = q < nv ? gm_V[q] : nullptr;
+        if (big(NQ)) k_gram<HDG_SSTEP_MAXV, true><<<nb, HDG_DOT_BLOCK, 0, stream>>>(NQ, vl, nv, d_part, mk);
+        else k_gram<HDG_SSTEP_MAXV, false><<<nb, HDG_DOT_BLOCK, 0, stream>>>(NQ, vl, nv, d_part, mk);
+        k_reduce_parts<<<npair, 256, 0, stream>>>(nb, npair, d_part, d_gram, direct ? h_gram : nullptr);
+        comm->allreduce_sum(d_gram, npair, stream);
+        n_reduce++;
+        if (!direct) HIPCHECK(hipMemcpyAsync(h_gram, d_gram, sizeof(double) * npair, hipMemcpyDeviceToHost, stream));
+        HIPCHECK(hipStreamSynchronize(stream));
+        G.assign((size_t)nv * nv, 0.0L);
+        {
+          int p = 0;
+          for (int a = 0; a < nv; a++) for (int c = a; c < nv; c++, p++) G[(size_t)a * nv + c] = G[(size_t)c * nv + a] = h_gram[p];
+        }
+        const double g00 = (double)G[0];
+        if (!(g00 == g00)) throw NotConverged{"s-step cycle: NaN residual"};
+        k0n = std::sqrt(std::max(g00, 0.0));
+        if (k0n <= target || k0n == 0.0) return its;  // the iterate the cycle started from had converged already
+        rank = sstep_ls(G, nv, built, yv, rho);
+        if (debug_on()) fprintf(stderr, "[sstep]   basis of %d (rank %d): |Mr|/|Mr0| %.3e, predicted %.3e\n", built, rank, k0n / beta0, rho / beta0);
+        // enough (with a margin for the accuracy of the prediction), rank deficient, or no room left: take the step
+        if (rho <= 0.7 * target || rank < built || built >= smax) break;
+        want = std::min(smax, built + std::max(1, length_for(rho / 0.7)));
+      }
+      n_sstep_cycles++;
+      Coefs cx, cr;
+      for (int i = 0; i < 32; i++) cx.c[i] = cr.c[i] = 0.0;
+      cr.c[0] = 1.0;
+      for (int i = 0; i < rank; i++) { cx.c[i] = (double)yv[i]; cr.c[i + 1] = -(double)yv[i]; }
+      tally(LC_VEC, bQ() * (nv + 3));
+      tally(LC_OTHER, 0.0);
+      {
+        const int nb = std::min(dot_blocks, vec_blocks(NQ));
+        VecList<HDG_SSTEP_MAXV> vl;
+        for (int q = 0; q < HDG_SSTEP_MAXV; q++) vl.p[q] = q < nv ? gm_V[q] : nullptr;
+        if (big(NQ)) k_sstep_update<HDG_SSTEP_MAXV, true><<<nb, HDG_DOT_BLOCK, 0, stream>>>(NQ, x, gm_V[0], vl, nv, cx, cr, d_part, mk);
+        else k_sstep_update<HDG_SSTEP_MAXV, false><<<nb, HDG_DOT_BLOCK, 0, stream>>>(NQ, x, gm_V[0], vl, nv, cx, cr, d_part, mk);
+        int dmin = fl.get(x);
+        for (int l = 0; l < nv; l++) dmin = std::min(dmin, fl.get(basis_key(l)));
+        fl.set(x, dmin);
+        fl.set(basis_key(0), dmin);
+        k_reduce_parts<<<1, 256, 0, stream>>>(nb, 1, d_part, d_gram, direct ? h_gram : nullptr);
+      }
+      comm->allreduce_sum(d_gram, 1, stream);
+      n_reduce++;
+      if (!direct) HIPCHECK(hipMemcpyAsync(h_gram, d_gram, sizeof(double), hipMemcpyDeviceToHost, stream));
+      HIPCHECK(hipStreamSynchronize(stream));
+      const double rn = std::sqrt(std::max(h_gram[0], 0.0));
+      if (!(rn == rn)) throw NotConverged{"s-step cycle: NaN residual"};
+      if (debug_on())
+        fprintf(stderr, "[sstep] cycle of %d (rank %d): |Mr|/|Mr0| %.3e -> %.3e (predicted %.3e)\n", built, rank, k0n / beta0, rn / beta0, rho / beta0);
+      if (rn <= target) return its;
+      if (its >= cfg.tent_maxit) throw NotConverged{"tentative-velocity s-step iteration reached max iterations"};
+      weak = (rn > 0.5 * k0n) ? weak + 1 : 0;
+      if (weak >= 2 || rank == 0) {
+        n_sstep_fallbacks++;
+        if (debug_on()) fprintf(stderr, "[sstep] two weak cycles: GMRES takes over\n");
+        return its + gmres(qstar, gamma, didx, b, x, rtol, cfg.tent_maxit, true, nullptr, 0, nullptr, nullptr, beta0);
+      }
+      cur = rn;
+      have_r = true;
+    }
+  }
+
   // Tentative-velocity solver (default): one short GMRES cycle, then Chebyshev iteration.
   // GMRES(4) needs as many iterations as GMRES(30) on this operator, i.e. the preconditioned iteration is
   // essentially stationary; a Chebyshev iteration reaches the same rate with NO inner products and no
@@ -2079,6 +2240,7 @@ struct Engine {
   std::vector<double> ch_widen;
   std::vector<int> ch_last;   // iterations of the last converged Chebyshev solve of the stage (check schedule)
   std::vector<char> ch_slow;  // the last Chebyshev solve of the stage was slow: GMRES until the next re-estimate
+  std::vector<int> ch_hand;   // learnt hand-over point of the stage: the check after which the Chebyshev rate last turned slow
   double* chd = nullptr;
   int cheb_gmres(const double* qstar, double gamma, int didx, const double* b, double* x) {
     FlowScope flow_(*this);
@@ -2091,6 +2253,7 @@ struct Engine {
     if ((int)ch_widen.size() < s + 1) ch_widen.assign(s + 1, 1.0);
     if ((int)ch_slow.size() < s + 1) ch_slow.assign(s + 1, 0);
     if ((int)ch_last.size() < s + 1) ch_last.assign(s + 1, 0);
+    if ((int)ch_hand.size() < s + 1) ch_hand.assign(s + 1, 0);
     std::vector<std::complex<double>> ritz;
     double beta0 = 0.0, beta = 0.0, lo, hi;
     int its = 0;
@@ -2099,6 +2262,7 @@ struct Engine {
     const bool estimate = ch_lmin[didx] <= 0 || (ch_count[didx] % est_every) == 0;
     ch_count[didx]++;
     if (estimate) {
+      ch_hand[didx] = 0;  // the hand-over point is learnt anew with the bounds
       its = gmres(qstar, gamma, didx, b, x, rtol, cfg.tent_maxit, true, &ritz, head_m, &beta0, &beta);
       if (beta <= rtol * beta0 || beta0 == 0.0) return its;
       lo = 1e300; hi = -1e300;
@@ -2124,6 +2288,14 @@ struct Engine {
       }
     } else {
       // bounds of this stage are known (refreshed every 16th solve): start the Chebyshev iteration at once
+      static const bool sstep_only = std::getenv("HDG_TENT_SSTEP_ONLY") != nullptr;  // experiment: no Chebyshev phase at all
+      if (sstep_only && !basis_f32 && !general) {
+        adv_apply(x, qstar, wQ2, gamma, b);
+        tent_precond(didx, wQ2, wQ1);
+        beta0 = std::sqrt(dot(NQ, wQ1, wQ1, KQ));
+        if (beta0 == 0.0) return 0;
+        return sstep_mr(qstar, gamma, didx, b, x, rtol, beta0, beta0);
+      }
       lo = ch_lmin[didx]; hi = ch_lmax[didx];
       adv_apply(x, qstar, wQ2, gamma, b);
       tent_precond(didx, wQ2, wQ1);
@@ -2185,8 +2357,10 @@ struct Engine {
       const int kfine = ch_last[didx] > 0 ? std::max(4, (ch_last[didx] - ch_head - 4) & ~1) : 0;
       static const int fine_step = std::getenv("HDG_CHEB_FINE_STEP") ? std::atoi(std::getenv("HDG_CHEB_FINE_STEP")) : 2;
       static const double handover_env = std::getenv("HDG_CHEB_HANDOVER") ? std::atof(std::getenv("HDG_CHEB_HANDOVER")) : -1.0;
-      // k = 2: 0.6; k >= 3 (the operator dominates, a GMRES iteration costs little more than a Chebyshev one): 0.4
-      const double handover = handover_env >= 0.0 ? handover_env : (cfg.tent_precond == 2 ? (cfg.degree >= 3 ? 0.4 : (cfg.degree == 2 ? 0.6 : 0.0)) : 0.0);
+      // k = 2: 0.3 with the s-step tail of round 4 (scan at C3, ms/step: 0.1-0.3: 85.5-85.8, 0.35: 91.2, 0.45: 95.6, 0.6: 95.1, 0.8:
+      // 100.8; with the GMRES(8) tail of round 3 the optimum was 0.6); k >= 3: 0.4 (no sensitivity between 0.25 and 0.6); k = 1: off
+      static const bool tail_gm = std::getenv("HDG_TAIL_GMRES") != nullptr;
+      const double handover = handover_env >= 0.0 ? handover_env : (cfg.tent_precond == 2 ? (cfg.degree >= 3 ? 0.4 : (cfg.degree == 2 ? (tail_gm ? 0.6 : 0.3) : 0.0)) : 0.0);
       const bool check = kfine > 0 ? (k < kfine ? (k % 8 == 0) : ((k - kfine) % fine_step == 0)) : (k % 4 == 0);
       const double rn = 1.0 / (2.0 * sigma - rho);
       adv_apply(cur, qstar, t, gamma, b);
@@ -2229,8 +2403,17 @@ struct Engine {
           // imaginary parts that the ellipse leaves out; a GMRES iteration costs 2-3 Chebyshev iterations (Krylov basis
           // traffic) but removes exactly those.  Hand over as soon as the observed rate is worse than what GMRES buys per
           // unit of cost, unless the end is a few iterations away anyway.
-          if (handover > 0.0 && k >= 6 && obs > handover && remaining > 6.0) tail = true;
+          static const int hand_min_k = std::getenv("HDG_CHEB_MIN_K") ? std::atoi(std::getenv("HDG_CHEB_MIN_K")) : 6;
+          if (handover > 0.0 && k >= hand_min_k && obs > handover && remaining > 6.0) tail = true;
+          if (tail) ch_hand[didx] = k_prev;  // the segment (k_prev, k] was the slow one: hand over at k_prev next time
         }
+        // round 4: with the s-step tail (an iteration of which costs what a Chebyshev iteration costs) the solves that follow
+        // hand over AT the learnt point instead of spending two more iterations on confirming the slow rate again
+        static const bool tail_gmres_ = std::getenv("HDG_TAIL_GMRES") != nullptr;
+        static const bool no_learn = std::getenv("HDG_CHEB_NO_LEARNT_HANDOVER") != nullptr;
+        if (!tail && !tail_gmres_ && !no_learn && !basis_f32 && !general && handover > 0.0 && ch_hand[didx] > 0 && k >= ch_hand[didx] &&
+            nz > rtol * beta0)
+          tail = true;
         k_prev = k; nz_prev = nz;
         const bool stalled = tail || stall_checks >= 8 || k > 6 * expected + 64;
         if (growing || stalled || its >= cfg.tent_maxit) {
@@ -2248,6 +2431,9 @@ struct Engine {
           finish_in_x();
           // the tail after a hand-over is 3-4 decades = 5-7 GMRES iterations: one cycle of 8, no restart in between
           static const int hand_cycle = std::getenv("HDG_CHEB_HAND_CYCLE") ? std::atoi(std::getenv("HDG_CHEB_HAND_CYCLE")) : 8;
+          // round 4: the tail as s-step minimal-residual cycles (no Gram-Schmidt passes); HDG_TAIL_GMRES restores the GMRES cycle
+          static const bool tail_gmres = std::getenv("HDG_TAIL_GMRES") != nullptr;
+          if (tail && !tail_gmres && !basis_f32 && !general) return its + sstep_mr(qstar, gamma, didx, b, x, rtol, beta0, nz);
           return its + gmres(qstar, gamma, didx, b, x, rtol, cfg.tent_maxit, true, nullptr, 0, nullptr, nullptr, beta0, tail ? hand_cycle : 4);
         }
         last = std::min(last, nz);

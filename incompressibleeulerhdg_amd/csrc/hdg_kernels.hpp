@@ -2302,6 +2302,134 @@ __global__ void k_reduce_parts(int nblocks, int nv, const double* __restrict__ p
     if (hres) hres[k] = tot;
   }
 }
+// coefficient list passed by value (Gram-Schmidt / basis updates)
+struct Coefs {
+  double c[32];
+};
+// ------------------------------------------------------------------------------------------
+// s-step minimal-residual cycle of the tentative-velocity solver (round 4; Engine::sstep_mr).  A GMRES iteration with
+// classical Gram-Schmidt reads the basis twice (inner products, update): 2j + 5 velocity-vector passes at step j, 60 for a
+// cycle of six -- more than the operator and the preconditioner of those six iterations.  Here the cycle first builds the
+// power basis K_0 = M(b - A x), K_i = (M A) K_{i-1} with no inner product at all, then ONE pass over the s + 1 vectors gives
+// their Gram matrix (k_gram), the host solves the (s x s) least-squares problem min |K_0 - sum y_i K_i|, and ONE more pass
+// forms x += sum y_i K_{i-1} and the new residual K_0 - sum y_i K_i together with its norm (k_sstep_update): 2 s + 5 passes
+// per cycle, 17 instead of 60 for s = 6.  A cycle whose predicted residual misses the target is EXTENDED (more basis vectors, the
+// Gram matrix once more) instead of restarted, up to s = 8: the iteration counts of GMRES(8) at a third of its vector traffic.
+// ------------------------------------------------------------------------------------------
+// Gram matrix of the first nv <= NV vectors over the owned entries: part[block * npair + p], npair = nv (nv + 1) / 2, pairs
+// (a <= b) in row-major order of the nv x nv upper triangle
+#define HDG_SSTEP_MAXV 9
+template <int NV, bool NT>
+__global__ __launch_bounds__(HDG_DOT_BLOCK) void k_gram(long N, const VecList<NV> V, int nv, double* __restrict__ part, RowMask mk) {
+  constexpr int NPAIR = NV * (NV + 1) / 2;
+  __shared__ double sm[HDG_DOT_BLOCK / 64][NPAIR];
+  double acc[NPAIR];
+#pragma unroll
+  for (int p = 0; p < NPAIR; p++) acc[p] = 0.0;
+  HDG_VEC_PROLOGUE
+  const bool same_row = (mk.w_ & 1) == 0;
+  for (long i = tid_; i < NP2_; i += stride_) {
+    double m0 = 1.0, m1 = 1.0;
+    if (mk.w_ > 0) {
+      m0 = row_factor(mk, N, 2 * i);
+      m1 = same_row ? m0 : row_factor(mk, N, 2 * i + 1);
+    }
+    hdg_d2 v[NV];
+#pragma unroll
+    for (int k = 0; k < NV; k++) v[k] = (k < nv) ? ldv<NT>(V.p[k], i) : hdg_d2{0.0, 0.0};
+    int p = 0;  // index in the FULL NV x NV triangle (compile-time after unrolling)
+#pragma unroll
+    for (int a = 0; a < NV; a++) {
+      const double ax = v[a].x * m0, ay = v[a].y * m1;
+#pragma unroll
+      for (int b = a; b < NV; b++, p++)
+        if (b < nv) acc[p] = fma(ay, v[b].y, fma(ax, v[b].x, acc[p]));
+    }
+  }
+  if (tail_) {
+    const double mf = mk.w_ > 0 ? row_factor(mk, N, it_) : 1.0;
+    int p = 0;
+#pragma unroll
+    for (int a = 0; a < NV; a++) {
+#pragma unroll
+      for (int b = a; b < NV; b++, p++)
+        if (b < nv) acc[p] = fma(mf * V.p[a][it_], V.p[b][it_], acc[p]);
+    }
+  }
+  const int lane = threadIdx.x & 63, wv_ = threadIdx.x >> 6;
+#pragma unroll
+  for (int p = 0; p < NPAIR; p++) {
+    const double s = wave_sum(acc[p]);
+    if (lane == 0) sm[wv_][p] = s;
+  }
+  __syncthreads();
+  // compact the full triangle to the nv x nv one
+  if (threadIdx.x < NPAIR) {
+    int a = 0, rem = threadIdx.x;
+    while (rem >= NV - a) { rem -= NV - a; a++; }
+    const int b = a + rem;
+    if (b < nv) {
+      double s = 0.0;
+      for (int w2 = 0; w2 < HDG_DOT_BLOCK / 64; w2++) s += sm[w2][threadIdx.x];
+      const int q = a * nv - a * (a - 1) / 2 + (b - a);
+      part[(long)blockIdx.x * (nv * (nv + 1) / 2) + q] = s;
+    }
+  }
+}
+// x += sum_{k<nv-1} cx[k] K_k;  K_0 <- sum_{k<nv} cr[k] K_k (the new preconditioned residual; whole arrays, ghost rows follow);
+// part[block] = the block's share of |new K_0|^2 over the owned entries
+template <int NV, bool NT>
+__global__ __launch_bounds__(HDG_DOT_BLOCK) void k_sstep_update(long N, double* __restrict__ x, double* __restrict__ k0, const VecList<NV> K, int nv,
+                                                                Coefs cx, Coefs cr, double* __restrict__ part, RowMask mk) {
+  __shared__ double sm[HDG_DOT_BLOCK / 64];
+  double acc = 0.0;
+  HDG_VEC_PROLOGUE
+  const bool same_row = (mk.w_ & 1) == 0;
+  for (long i = tid_; i < NP2_; i += stride_) {
+    double m0 = 1.0, m1 = 1.0;
+    if (mk.w_ > 0) {
+      m0 = row_factor(mk, N, 2 * i);
+      m1 = same_row ? m0 : row_factor(mk, N, 2 * i + 1);
+    }
+    hdg_d2 v[NV];
+    v[0] = ldv<NT>(k0, i);
+#pragma unroll
+    for (int k = 1; k < NV; k++) v[k] = (k < nv) ? ldv<NT>(K.p[k], i) : hdg_d2{0.0, 0.0};
+    hdg_d2 xv = ldv<NT>(x, i), r = hdg_d2{0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+      if (k < nv) {
+        r = fma2(cr.c[k], v[k], r);
+        if (k < nv - 1) xv = fma2(cx.c[k], v[k], xv);
+      }
+    }
+    stv<NT>(x, i, xv);
+    stv<NT>(k0, i, r);
+    acc = fma(m1 * r.y, r.y, fma(m0 * r.x, r.x, acc));
+  }
+  if (tail_) {
+    const double mf = mk.w_ > 0 ? row_factor(mk, N, it_) : 1.0;
+    double xv = x[it_], r = 0.0;
+    for (int k = 0; k < nv; k++) {
+      const double vk = k == 0 ? k0[it_] : K.p[k][it_];
+      r = fma(cr.c[k], vk, r);
+      if (k < nv - 1) xv = fma(cx.c[k], vk, xv);
+    }
+    x[it_] = xv;
+    k0[it_] = r;
+    acc = fma(mf * r, r, acc);
+  }
+  const int lane = threadIdx.x & 63, wv_ = threadIdx.x >> 6;
+  const double s = wave_sum(acc);
+  if (lane == 0) sm[wv_] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int w2 = 0; w2 < HDG_DOT_BLOCK / 64; w2++) t += sm[w2];
+    part[blockIdx.x] = t;
+  }
+}
+
 // Chebyshev step on velocity vectors, three-term form:  pn = x + c1 (x - pn) + c2 z   (pn: x_{n-1} -> x_{n+1})
 template <bool NT>
 __global__ void k_cheb_update(long N, double* __restrict__ pn, const double* __restrict__ z, const double* __restrict__ x,
@@ -2320,9 +2448,6 @@ __global__ void k_cheb_update(long N, double* __restrict__ pn, const double* __r
 }
 
 // coefficients passed by value (kernel arguments): no host->device copy, no extra sync
-struct Coefs {
-  double c[32];
-};
 // out = scale * (w - sum_k h[k] V[k])     (classical Gram-Schmidt update fused with the normalisation)
 // TV = float (single-precision basis storage): the new vector is ROUNDED to single precision, stored in outf, and out
 // receives the same rounded values as doubles (the operator kernels read doubles): the Arnoldi relation then holds for

@@ -66,7 +66,7 @@ for what, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
         k = [n for n in t if n.startswith("k_axpby<true>")]  # the velocity-sized launches (streaming cache policy)
         if k:
             cal[ctr] = t[k[0]][ctr]
-def rows_per_plane(nx, ny, gh=4):  # Engine::construct: ghost rows + the stride padding rule
+def rows_per_plane(nx, ny, gh=6):  # Engine::construct: ghost rows + the stride padding rule
     R = ny + 2 * gh
     for pad in range(64):
         t = ((2 * nx * (R + pad) * 16) % 524288) / 32768.0
