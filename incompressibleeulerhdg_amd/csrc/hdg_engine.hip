@@ -1175,6 +1175,12 @@ struct Engine {
   static int mfma_min_degree() { static const int d = std::getenv("HDG_MFMA_K2") ? 2 : 3; return d; }
   const bool lift_pair_off = std::getenv("HDG_LIFT_NO_PAIR") != nullptr;  // read when an engine is built (tests compare the two forms)
   bool lift_pair() const { return !lift_pair_off && K <= 2 && bs() == 128 && !general; }
+  // paired form of the advection kernel (round 4; HDG_ADV_PAIR=1 / 0 switches it, read when an engine is built)
+  const int adv_pair_env = std::getenv("HDG_ADV_PAIR") ? std::atoi(std::getenv("HDG_ADV_PAIR")) : -1;
+  bool adv_pair() const {
+    const bool dflt = false;  // measured: see DESIGN.md section 9
+    return (adv_pair_env >= 0 ? adv_pair_env != 0 : dflt) && K <= 2 && bs() == 128 && !general && dt.nqe == (3 * K + 5) / 2;
+  }
   void lift_mfma(const Geo& gx, const double* t0, const double* t1, const double* in, double* out, double* chd_ = nullptr,
                  const double* chx_ = nullptr, double c1 = 0.0, double c2 = 0.0) {
     const dim3 grid(8 * gx.rows_xcd * 2);
@@ -1315,6 +1321,15 @@ struct Engine {
       } else if (two_lane) {
         const int cpb = bs() / 2, nbx2 = (g.nx + cpb - 1) / cpb;
         HDG_DISPATCH(k_adv_apply2<KK><<<dim3(8 * g.rows_xcd * 2 * nbx2), bs(), 0, stream>>>(g, dt, x, qstar, out, gamma, up, bsub));
+      } else if (adv_pair()) {
+        // k <= 2, 128-thread workgroups: both triangles of 64 squares per workgroup, neighbour traces through LDS
+        if (K == 1) {
+          if (bsub) k_adv_pair<1, true><<<cell_grid_of(g), 128, 0, stream>>>(g, dt, x, qstar, out, gamma, up, bsub);
+          else k_adv_pair<1, false><<<cell_grid_of(g), 128, 0, stream>>>(g, dt, x, qstar, out, gamma, up, bsub);
+        } else {
+          if (bsub) k_adv_pair<2, true><<<cell_grid_of(g), 128, 0, stream>>>(g, dt, x, qstar, out, gamma, up, bsub);
+          else k_adv_pair<2, false><<<cell_grid_of(g), 128, 0, stream>>>(g, dt, x, qstar, out, gamma, up, bsub);
+        }
       } else if (bsub) {
         HDG_DISPATCH(k_adv_apply<KK, true><<<cell_grid_of(g), bs(), 0, stream>>>(g, dt, x, qstar, out, gamma, up, bsub));
       } else {
@@ -2164,10 +2179,16 @@ struct Engine {
         const int nb = std::min(std::min(dot_blocks, vec_blocks(NQ)), (dot_blocks * MAXV) / npair);
         tally(LC_DOT, bQ() * nv);
         tally(LC_OTHER, 0.0);
-        VecList<HDG_SSTEP_MAXV> vl;
-        for (int q = 0; q < HDG_SSTEP_MAXV; q++) vl.p[q] = q < nv ? gm_V[q] : nullptr;
-        if (big(NQ)) k_gram<HDG_SSTEP_MAXV, true><<<nb, HDG_DOT_BLOCK, 0, stream>>>(NQ, vl, nv, d_part, mk);
-        else k_gram<HDG_SSTEP_MAXV, false><<<nb, HDG_DOT_BLOCK, 0, stream>>>(NQ, vl, nv, d_part, mk);
+        // two instantiations: up to 7 vectors (s <= 6, the default: 28 accumulators, 3 waves / SIMD) and up to 9 (244 VGPRs)
+        auto gram = [&](auto tag) {
+          constexpr int NV = decltype(tag)::value;
+          VecList<NV> vl;
+          for (int q = 0; q < NV; q++) vl.p[q] = q < nv ? gm_V[q] : nullptr;
+          if (big(NQ)) k_gram<NV, true><<<nb, HDG_DOT_BLOCK, 0, stream>>>(NQ, vl, nv, d_part, mk);
+          else k_gram<NV, false><<<nb, HDG_DOT_BLOCK, 0, stream>>>(NQ, vl, nv, d_part, mk);
+        };
+        if (nv <= 7) gram(std::integral_constant<int, 7>{});
+        else gram(std::integral_constant<int, HDG_SSTEP_MAXV>{});
         k_reduce_parts<<<npair, 256, 0, stream>>>(nb, npair, d_part, d_gram, direct ? h_gram : nullptr);
         comm->allreduce_sum(d_gram, npair, stream);
         n_reduce++;

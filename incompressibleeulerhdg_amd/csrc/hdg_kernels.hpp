@@ -879,6 +879,173 @@ void k_adv_apply(Geo g, DevTables T, const double* __restrict__ xin,
 }
 
 // ------------------------------------------------------------------------------------------
+// K3 in PAIRED form (round 4; k <= 2, 128-thread workgroups; the mapping of k_edge_lift_pair): a workgroup holds BOTH
+// triangles of 64 squares of a row -- wave 0 the lower-left cells, wave 1 the upper-right ones; the shape stays wave uniform,
+// so every table is still a scalar load.  The facet terms need the NEIGHBOUR'S trace at the edge quadrature points; across
+// edges 1 (same square) and 2 (the square to the left / right) the neighbour lives in the other wave, and its trace at those
+// points is what that cell evaluates for itself anyway (the local edge numbers of the two cells of an edge agree, and both
+// tabulate the edge at the same physical points in the same order: k_adv_apply evaluates the neighbour with ePhi[1-s][e], the
+// neighbour's own table).  So the two waves exchange 2 edges x NQE points x 2 components through LDS instead of gathering each
+// other's 2 NU coefficients and repeating the 2 NU NQE products: per cell 40 of the 100 sixteen-byte loads and 200 of ~2 800
+// FMAs (k = 2) go away.  Only the neighbour across edge 0 (the row below / above) is gathered, its loads issued with the cell's
+// own; the first / last live lane of a wave, whose edge-2 neighbour lies in the next workgroup, gathers that one cell into the
+// SAME registers once edge 0 is done (the cell term covers the latency).  Same arithmetic per output entry as k_adv_apply (the
+// neighbour trace is the same sum, formed by the other thread); order of the facet terms: 0, 2, 1.
+// ------------------------------------------------------------------------------------------
+template <int K, bool RESID>
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(HDG_ADV_WAVES)))
+void k_adv_pair(Geo g, DevTables T, const double* __restrict__ xin, const double* __restrict__ qstar, double* __restrict__ out,
+                double gamma, double upwind, const double* __restrict__ bsub_) {
+  constexpr int NU = Dim<K>::NU, N2 = 2 * NU, NQE = (3 * K + 5) / 2;
+  __shared__ double tr[2][2][2 * NQE][64];  // [shape][edge 1, 2][x-trace at the NQE points, y-trace][lane]
+  const double* __restrict__ bsub = RESID ? bsub_ : nullptr;
+  const int xcd_ = blockIdx.x & 7, q_ = blockIdx.x >> 3;
+  const int jj_ = q_ / (2 * g.nbx), rem_ = q_ - jj_ * 2 * g.nbx;
+  const int s = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = (int)(threadIdx.x & 63);
+  const int i0 = rem_ * 64, i = i0 + lane;
+  const int r_ = xcd_ * g.rows_xcd + jj_;
+  const int j = launch_row(g, r_);
+  if (jj_ >= g.rows_xcd || r_ >= g.wrows || i0 >= g.nx) return;  // whole workgroup
+  const bool live = i < g.nx;
+  const int ic = live ? i : g.nx - 1;  // clamped: loads stay in bounds, nothing is stored for dead lanes
+  const long c = rowbase(g, s, j) + ic;
+  const int ilast = min(i0 + 63, g.nx - 1);
+  long cn0 = 0, cnx = 0;
+  const bool has0 = nbr(s, 0, ic, j, g, cn0);
+  const bool has2 = !g.dbg_nonbr && (s == 0 ? (ic > 0 || g.px) : (ic < g.nx - 1 || g.px));
+  const bool outer = live && has2 && (s == 0 ? lane == 0 : ic == ilast);  // its edge-2 neighbour is not in this workgroup
+  if (outer) { long t; nbr(s, 2, ic, j, g, t); cnx = t; }
+  double x[N2], qs[N2], F[N2], xa[N2];
+  load_vel<NU>(xin, g.Nc, c, x);
+#if HDG_ADV_NT & 1
+  load_vel_nt<NU>(qstar, g.Nc, c, qs);
+#else
+  load_vel<NU>(qstar, g.Nc, c, qs);
+#endif
+  load_vel<NU>(xin, g.Nc, cn0, xa);  // unconditional (a boundary edge points into a ghost row: inside the vector)
+  // own traces at the quadrature points of edges 1 and 2: published for the other wave
+#pragma unroll
+  for (int e = 1; e < 3; e++) {
+    const double* __restrict__ Po = T.ePhi[s][e];
+#pragma unroll 1
+    for (int q = 0; q < NQE; q++) {
+      double ox = 0, oy = 0;
+#pragma unroll
+      for (int m = 0; m < NU; m++) {
+        const double po = Po[q * NU + m];
+        ox = fma(po, x[m], ox);
+        oy = fma(po, x[NU + m], oy);
+      }
+      tr[s][e - 1][q][lane] = ox;
+      tr[s][e - 1][NQE + q][lane] = oy;
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < N2; n++) F[n] = 0.0;
+  // ---- facet term of edge 0 (gathered neighbour)
+  adv_facet<K>(T, s, 0, has0, upwind, x, qs, xa, F);
+  // the one lane whose edge-2 neighbour lies in the next workgroup gathers it now (xa is free; consumed after the cell term)
+  if (outer) load_vel<NU>(xin, g.Nc, cnx, xa);
+  // ---- cell term
+  {
+    const double* __restrict__ Phi = T.cPhi[s];
+    const double* __restrict__ Gx = T.cGx[s];
+    const double* __restrict__ Gy = T.cGy[s];
+    const int nq = T.nqc;
+#pragma unroll 1
+    for (int q = 0; q < nq; q++) {
+      double qx = 0, qy = 0, dxx = 0, dxy = 0, dyx = 0, dyy = 0;  // dab = d_b x_a
+#pragma unroll
+      for (int m = 0; m < NU; m++) {
+        const double ph = Phi[q * NU + m], gx = Gx[q * NU + m], gy = Gy[q * NU + m];
+        qx = fma(ph, qs[m], qx);
+        qy = fma(ph, qs[NU + m], qy);
+        dxx = fma(gx, x[m], dxx);
+        dxy = fma(gy, x[m], dxy);
+        dyx = fma(gx, x[NU + m], dyx);
+        dyy = fma(gy, x[NU + m], dyy);
+      }
+      const double w = T.cw[q];
+      const double ax = -w * (qx * dxx + qy * dxy);
+      const double ay = -w * (qx * dyx + qy * dyy);
+#pragma unroll
+      for (int m = 0; m < NU; m++) {
+        const double ph = Phi[q * NU + m];
+        F[m] = fma(ph, ax, F[m]);
+        F[NU + m] = fma(ph, ay, F[NU + m]);
+      }
+    }
+  }
+  __syncthreads();
+  // ---- facet terms of edges 2 and 1: the neighbour's trace from LDS
+#pragma unroll
+  for (int ee = 0; ee < 2; ee++) {
+    const int e = 2 - ee;
+    const double* __restrict__ Po = T.ePhi[s][e];
+    const double* __restrict__ Pn = T.ePhi[1 - s][e];
+    const double nx_ = T.enx[e], ny_ = T.eny[e], sg = T.sig[s][e];
+    const double pen = T.alpha / T.elen[e];
+    const bool has = e == 1 ? !g.dbg_nonbr : has2;
+    // edge 2: shape 0 faces the upper-right cell of the square to the left, shape 1 the lower-left cell of the square to the right
+    const int ln = e == 1 ? lane : (s == 0 ? max(lane - 1, 0) : min(lane + 1, 63));
+    const bool any_outer = e == 2 && __builtin_amdgcn_ballot_w64(outer) != 0;  // wave uniform
+#pragma unroll 1
+    for (int q = 0; q < NQE; q++) {
+      const double ox = tr[s][e - 1][q][lane], oy = tr[s][e - 1][NQE + q][lane];
+      double bx = tr[1 - s][e - 1][q][ln], by = tr[1 - s][e - 1][NQE + q][ln];
+      double qn = 0;
+#pragma unroll
+      for (int m = 0; m < NU; m++) qn = fma(Po[q * NU + m], fma(nx_, qs[m], ny_ * qs[NU + m]), qn);
+      if (any_outer) {  // at most one lane per wave: its neighbour's trace from the gathered coefficients
+        double gx_ = 0, gy_ = 0;
+#pragma unroll
+        for (int m = 0; m < NU; m++) {
+          const double pn = Pn[q * NU + m];
+          gx_ = fma(pn, xa[m], gx_);
+          gy_ = fma(pn, xa[NU + m], gy_);
+        }
+        bx = outer ? gx_ : bx;
+        by = outer ? gy_ : by;
+      }
+      if (!has) bx = by = 0.0;
+      const double w = T.ew[e][q];
+      const double cf = has ? w * (0.5 * sg * qn - upwind * fabs(qn)) : 0.0;
+      const double jx = ox - bx, jy = oy - by;
+      const double jn = (jx * nx_ + jy * ny_) * pen * w;
+      const double vx = cf * jx - jn * nx_;
+      const double vy = cf * jy - jn * ny_;
+#pragma unroll
+      for (int m = 0; m < NU; m++) {
+        const double po = Po[q * NU + m];
+        F[m] = fma(po, vx, F[m]);
+        F[NU + m] = fma(po, vy, F[NU + m]);
+      }
+    }
+    if (e == 2 && bsub) {  // xa is free now: the right-hand side of the residual form, requested before the last facet term
+#if HDG_ADV_NT & 2
+      load_vel_nt<NU>(bsub, g.Nc, c, xa);
+#else
+      load_vel<NU>(bsub, g.Nc, c, xa);
+#endif
+    }
+  }
+  if (!live) return;
+  if (bsub) {
+#pragma unroll
+    for (int n = 0; n < N2; n++) F[n] = xa[n] - fma(-gamma, F[n], x[n]);
+  } else {
+#pragma unroll
+    for (int n = 0; n < N2; n++) F[n] = fma(-gamma, F[n], x[n]);
+  }
+#if HDG_ADV_NT & 4
+  store_vel_nt<NU>(out, g.Nc, c, F);
+#else
+  store_vel<NU>(out, g.Nc, c, F);
+#endif
+}
+
+// ------------------------------------------------------------------------------------------
 // K3, two lanes per cell (used for k >= 3): lane parity = velocity component a.  Every table of this kernel
 // (cell / edge basis tabulations) is the same for both components, so the table operands stay wave uniform
 // (SGPR); only two quantities couple the components and cross the lane pair with one DPP swap each:
