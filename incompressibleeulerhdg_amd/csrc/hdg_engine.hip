@@ -270,6 +270,13 @@ struct Engine {
     DevCsr Pi, Wdiv, Bdiv, Gp, Gl, Rq, Rp, Rb, Cq, Cqi, Cp, Cpi, Cl, Cli, Psi_p, Psi_l, Mu_u, Mu_p, Mu_l;
   } gd;
   std::vector<DevCsr> gdinv;  // element block-Jacobi per stage
+  // matrix-free lift on general meshes (k_g_lift, round 4): reference moment tables, per-cell lifting tables of the BDM
+  // projection and (per stage) of the hybrid preconditioner; HDG_GENERAL_CSR_LIFT keeps the assembled operators
+  const bool g_csr_lift = std::getenv("HDG_GENERAL_CSR_LIFT") != nullptr;  // read when an engine is built
+  const double* g_nref = nullptr;
+  const double* g_lift = nullptr;
+  std::vector<const double*> g_hyb;
+
   GGeo ggeo;
   const double *d_one_p = nullptr, *d_int_p = nullptr, *d_one_l = nullptr;
   const int* upload_ints(const std::vector<int>& v) {
@@ -416,7 +423,11 @@ struct Engine {
     // trace system: Chebyshev(2) / edge block-Jacobi + the P1 coarse space with an algebraic V-cycle (hdg_amg.hpp);
     // HDG_GENERAL_NO_COARSE: the edge block-Jacobi alone
     // tentative velocity: GMRES(30) with the hybrid preconditioner Pi + Dinv (I - Pi) (HDG_GENERAL_BLOCK_JACOBI: Dinv alone)
-    cfg.tent_precond = std::getenv("HDG_GENERAL_BLOCK_JACOBI") ? 0 : 2; cfg.tent_solver = 0; cfg.periodic = 0;
+    // round 4: the Chebyshev iteration + s-step tail of the structured engine here as well (preconditioner and Chebyshev step as
+    // separate launches: the assembled operators have no fused form); HDG_GENERAL_GMRES restores GMRES(30)
+    cfg.tent_precond = std::getenv("HDG_GENERAL_BLOCK_JACOBI") ? 0 : 2; cfg.periodic = 0;
+    // (k = 1: GMRES -- with assembled operators an iteration is dear, and the Chebyshev iteration needs 41 where GMRES needs 33)
+    cfg.tent_solver = (std::getenv("HDG_GENERAL_GMRES") || cfg.tent_precond != 2 || K < 2) ? 0 : 1;
     cfg.trace_precond = std::getenv("HDG_GENERAL_NO_COARSE") ? 0 : 1;
     cfg.gmres_restart = std::max(cfg.gmres_restart, 30);
     gm = new GMesh();
@@ -445,6 +456,13 @@ struct Engine {
     gd.Cp = upload_csr(gops.Cp); gd.Cpi = upload_csr(gops.Cpi); gd.Cl = upload_csr(gops.Cl); gd.Cli = upload_csr(gops.Cli);
     d_one_p = upload(gops.one_p); d_int_p = upload(gops.int_p); d_one_l = upload(gops.one_l);
     gdinv.assign((size_t)s, DevCsr());
+    g_hyb.assign((size_t)s, nullptr);
+    if (!g_csr_lift) {
+      dvec nr(gtab->Nref.size());
+      for (size_t q = 0; q < nr.size(); q++) nr[q] = (double)gtab->Nref[q];
+      g_nref = upload(nr);
+      g_lift = upload(assemble_lift_tables(*gtab, *gm, gloc, -1.0));
+    }
     {
       const GMesh& M = *gm;
       dvec isd((size_t)M.nc), celen((size_t)3 * M.nc), cenx((size_t)3 * M.nc), ceny((size_t)3 * M.nc);
@@ -1200,8 +1218,16 @@ struct Engine {
       default: throw std::string("MFMA lift: degree out of range");
     }
   }
+  void g_lift_apply(const double* Gt, const double* x, double* out) {
+    tally(LC_LIFT, 2 * bQ() + 8.0 * (double)gm->nc * 2 * NU * 3 * NE);
+    HDG_DISPATCH(k_g_lift<KK><<<(gm->nc + 63) / 64, 64, 0, stream>>>(ggeo, g_nref, Gt, x, out));
+  }
   void bdm(const double* in, double* out) {
-    if (general) { csr(gd.Pi, in, 1.0, 0.0, out); return; }
+    if (general) {
+      if (g_lift) g_lift_apply(g_lift, in, out);
+      else csr(gd.Pi, in, 1.0, 0.0, out);
+      return;
+    }
     const int ext = stencil_in(in, FQ);
     const Geo gx = g_ext(ext);
     fl.set(out, ext);
@@ -1812,8 +1838,9 @@ struct Engine {
   // ------------------------------------------------------------------ tentative velocity solve
   void ensure_dinv(int idx, double gamma) {
     if (general) {
-      if (dinv_gamma[idx] == gamma && gdinv[(size_t)idx].nrows) return;
-      gdinv[(size_t)idx] = upload_csr(assemble_block_jacobi(*gtab, *gm, gloc, gamma));
+      if (dinv_gamma[idx] == gamma && (gdinv[(size_t)idx].nrows || g_hyb[(size_t)idx])) return;
+      if (!g_csr_lift && cfg.tent_precond == 2) g_hyb[(size_t)idx] = upload(assemble_lift_tables(*gtab, *gm, gloc, gamma));
+      else gdinv[(size_t)idx] = upload_csr(assemble_block_jacobi(*gtab, *gm, gloc, gamma));
       dinv_gamma[idx] = gamma;
       return;
     }
@@ -1862,7 +1889,9 @@ struct Engine {
   // z = M r  (tentative-velocity preconditioner)
   void tent_precond(int didx, const double* r, double* z) {
     if (general) {
-      if (cfg.tent_precond == 2) {
+      if (cfg.tent_precond == 2 && g_hyb[(size_t)didx]) {
+        g_lift_apply(g_hyb[(size_t)didx], r, z);  // z = r + (I - Dinv) Lift d(r): one matrix-free kernel
+      } else if (cfg.tent_precond == 2) {
         // hybrid two-level preconditioner Pi + Dinv (I - Pi): the H(div)-conforming part is left alone (mass matrix =
         // identity), the element block-Jacobi acts on the rest, which carries the normal-jump penalty
         csr(gd.Pi, r, 1.0, 0.0, wQ3);
@@ -1890,6 +1919,12 @@ struct Engine {
   // cell_norm (hybrid preconditioner only): instead of z the kernel writes |z_K|^2 per cell into cell_ss
   void tent_precond_cheb(int didx, const double* r, double* zout, double* d_, double* x_, double c1, double c2,
                          bool cell_norm = false) {
+    if (general) {  // assembled preconditioner, then the step as a vector kernel
+      double* zz = zout ? zout : wQ1;  // (tent_precond uses wQ3 / wQ4 as its own scratch; wQ1 is the solver's z buffer)
+      tent_precond(didx, r, zz);
+      cheb_update(d_, zz, x_, c1, c2);
+      return;
+    }
     if (cfg.tent_precond == 0) {
       blockdiag(dinv0[didx], dinv1[didx], r, nullptr, 0.0, wQ4);
       if (zout) copy(zout, wQ4, NQ);
@@ -2310,7 +2345,7 @@ struct Engine {
     } else {
       // bounds of this stage are known (refreshed every 16th solve): start the Chebyshev iteration at once
       static const bool sstep_only = std::getenv("HDG_TENT_SSTEP_ONLY") != nullptr;  // experiment: no Chebyshev phase at all
-      if (sstep_only && !basis_f32 && !general) {
+      if (sstep_only && !basis_f32) {
         adv_apply(x, qstar, wQ2, gamma, b);
         tent_precond(didx, wQ2, wQ1);
         beta0 = std::sqrt(dot(NQ, wQ1, wQ1, KQ));
@@ -2386,7 +2421,7 @@ struct Engine {
       const double rn = 1.0 / (2.0 * sigma - rho);
       adv_apply(cur, qstar, t, gamma, b);
       // hybrid preconditioner: the lift kernel emits |z_K|^2 per cell (N_c doubles) instead of z (N_Q doubles)
-      const bool cell_norm = check && cfg.tent_precond == 2 && !use_mfma_lift();
+      const bool cell_norm = check && cfg.tent_precond == 2 && !use_mfma_lift() && !general;
       tent_precond_cheb(didx, t, (check && !cell_norm) ? z : nullptr, oth, cur, rn * rho, 2.0 * rn / delta, cell_norm);
       std::swap(cur, oth);
       rho = rn;
@@ -2432,7 +2467,7 @@ struct Engine {
         // hand over AT the learnt point instead of spending two more iterations on confirming the slow rate again
         static const bool tail_gmres_ = std::getenv("HDG_TAIL_GMRES") != nullptr;
         static const bool no_learn = std::getenv("HDG_CHEB_NO_LEARNT_HANDOVER") != nullptr;
-        if (!tail && !tail_gmres_ && !no_learn && !basis_f32 && !general && handover > 0.0 && ch_hand[didx] > 0 && k >= ch_hand[didx] &&
+        if (!tail && !tail_gmres_ && !no_learn && !basis_f32 && handover > 0.0 && ch_hand[didx] > 0 && k >= ch_hand[didx] &&
             nz > rtol * beta0)
           tail = true;
         k_prev = k; nz_prev = nz;
@@ -2454,7 +2489,7 @@ struct Engine {
           static const int hand_cycle = std::getenv("HDG_CHEB_HAND_CYCLE") ? std::atoi(std::getenv("HDG_CHEB_HAND_CYCLE")) : 8;
           // round 4: the tail as s-step minimal-residual cycles (no Gram-Schmidt passes); HDG_TAIL_GMRES restores the GMRES cycle
           static const bool tail_gmres = std::getenv("HDG_TAIL_GMRES") != nullptr;
-          if (tail && !tail_gmres && !basis_f32 && !general) return its + sstep_mr(qstar, gamma, didx, b, x, rtol, beta0, nz);
+          if (tail && !tail_gmres && !basis_f32) return its + sstep_mr(qstar, gamma, didx, b, x, rtol, beta0, nz);
           return its + gmres(qstar, gamma, didx, b, x, rtol, cfg.tent_maxit, true, nullptr, 0, nullptr, nullptr, beta0, tail ? hand_cycle : 4);
         }
         last = std::min(last, nz);

@@ -753,4 +753,44 @@ inline Csr assemble_block_jacobi(const GeneralTables& T, const GMesh& M, const s
   return D.build();
 }
 
+// Lifting tables of the MATRIX-FREE BDM projection / hybrid preconditioner on a general triangulation (round 4; k_g_lift):
+//   out_K = x_K + G_K d_K,   d_K = the 3 ne edge-moment defects of the cell (w (N^{K'} x_K' - N^K x_K); boundary: -N^K x_K),
+//   gamma < 0:  G_K = Lift_K                                  (BDM projection, common.py:91-108)
+//   gamma >= 0: G_K = (I - Dinv_K) Lift_K,  Dinv_K = (I + gamma sum_e alpha / len_e N_e^T N_e)^-1   (hybrid preconditioner
+//               Pi + Dinv (I - Pi) of the tentative velocity: the conforming part is kept, the rest goes through the element block-Jacobi)
+// n2 x 3 ne doubles per cell in cell-fastest order Gt[(r * 3 ne + l * ne + a) * nc + c] (coalesced across the cells of a wave):
+// 1.9 KB per cell at k = 2 where the assembled projection holds 19 KB per cell.
+inline std::vector<double> assemble_lift_tables(const GeneralTables& T, const GMesh& M, const std::vector<CellLocal>& loc, double gamma) {
+  const int n2 = T.n2, ne = T.ne, nm = 3 * ne;
+  std::vector<double> Gt((size_t)M.nc * n2 * nm);
+  parallel_for(M.nc, [&](int c) {
+    std::vector<real> Lm((size_t)n2 * nm), Gm((size_t)n2 * nm);
+    for (int l = 0; l < 3; l++)
+      for (int r = 0; r < n2; r++)
+        for (int a = 0; a < ne; a++) Lm[(size_t)r * nm + l * ne + a] = loc[(size_t)c].Lift[l][(size_t)r * ne + a];
+    if (gamma < 0) Gm = Lm;
+    else {
+      std::vector<real> Dm((size_t)n2 * n2, 0);
+      for (int i = 0; i < n2; i++) Dm[(size_t)i * n2 + i] = 1;
+      for (int l = 0; l < 3; l++) {
+        const real f = (real)gamma * (real)T.alpha / (real)M.elen[M.cedge[3 * (size_t)c + l]];
+        for (int a = 0; a < ne; a++)
+          for (int r = 0; r < n2; r++)
+            for (int cc = 0; cc < n2; cc++)
+              Dm[(size_t)r * n2 + cc] += f * loc[(size_t)c].N[l][(size_t)a * n2 + r] * loc[(size_t)c].N[l][(size_t)a * n2 + cc];
+      }
+      invert(n2, Dm);
+      for (int r = 0; r < n2; r++)
+        for (int q = 0; q < nm; q++) {
+          real acc = Lm[(size_t)r * nm + q];
+          for (int cc = 0; cc < n2; cc++) acc -= Dm[(size_t)r * n2 + cc] * Lm[(size_t)cc * nm + q];
+          Gm[(size_t)r * nm + q] = acc;
+        }
+    }
+    for (int r = 0; r < n2; r++)
+      for (int q = 0; q < nm; q++) Gt[((size_t)r * nm + q) * M.nc + c] = (double)Gm[(size_t)r * nm + q];
+  });
+  return Gt;
+}
+
 }  // namespace hdg

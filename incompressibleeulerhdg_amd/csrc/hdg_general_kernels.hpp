@@ -127,6 +127,60 @@ __global__ __launch_bounds__(64) void k_g_adv(GGeo G, const double* __restrict__
   }
 }
 
+// BDM projection / hybrid two-level preconditioner on a general triangulation, MATRIX FREE (round 4; the assembled form is one
+// CSR product with 80-entry rows, 19 KB of matrix per cell at k = 2: 45 % of a Kelvin-Helmholtz step on the level-6 disk):
+//   out_K = x_K + G_K d_K,   d_K[l] = w (N_l^{K'} x_K' - N_l^K x_K)  (interior, w = 1/2),   -N_l^K x_K  (boundary),
+// N_l^K = sqrt(len_l / detJ_K) Nref[l, flip] (n_x | n_y) with the FIXED edge normal (hdg_general.hpp: cell_edge_blocks): the
+// moment tables are 6 reference tabulations (local edge x orientation) staged in LDS -- a lane picks its own and its
+// neighbour's variant -- scaled by per-cell geometry; G_K (hdg_general.hpp: assemble_lift_tables) is the one per-cell matrix
+// that remains, n2 x 3 ne doubles read coalesced across the cells of a wave.
+template <int K>
+__global__ __launch_bounds__(64) void k_g_lift(GGeo G, const double* __restrict__ Nref, const double* __restrict__ Gt,
+                                               const double* __restrict__ xin, double* __restrict__ out) {
+  constexpr int NU = Dim<K>::NU, N2 = 2 * NU, NE = Dim<K>::NE, NM = 3 * NE;
+  __shared__ double Ns[6 * NE * NU];
+  for (int q = threadIdx.x; q < 6 * NE * NU; q += 64) Ns[q] = Nref[q];
+  __syncthreads();
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= G.nc) return;
+  double x[N2], d[NM];
+#pragma unroll
+  for (int n = 0; n < N2; n++) x[n] = xin[(long)c * N2 + n];
+  const double s = G.inv_sdet[c];
+#pragma unroll
+  for (int l = 0; l < 3; l++) {
+    const int cn = G.cnbr[3 * (long)c + l];
+    const bool has = cn >= 0;
+    const double nx_ = G.cenx[3 * (long)c + l], ny_ = G.ceny[3 * (long)c + l], sl = sqrt(G.celen[3 * (long)c + l]);
+    const double* __restrict__ No = Ns + G.ctab[3 * (long)c + l] * NE * NU;
+    const double* __restrict__ Nn = Ns + (has ? G.ntab[3 * (long)c + l] : 0) * NE * NU;
+    const double so = sl * s, sn = has ? sl * G.inv_sdet[cn] : 0.0;
+    double xo[NU], xb[NU];  // normal components n . x_m of the own and of the neighbour's coefficients
+#pragma unroll
+    for (int m = 0; m < NU; m++) {
+      xo[m] = fma(nx_, x[m], ny_ * x[NU + m]);
+      xb[m] = has ? fma(nx_, xin[(long)cn * N2 + m], ny_ * xin[(long)cn * N2 + NU + m]) : 0.0;
+    }
+#pragma unroll
+    for (int a = 0; a < NE; a++) {
+      double own = 0.0, nb = 0.0;
+#pragma unroll
+      for (int m = 0; m < NU; m++) {
+        own = fma(No[a * NU + m], xo[m], own);
+        nb = fma(Nn[a * NU + m], xb[m], nb);
+      }
+      d[l * NE + a] = has ? 0.5 * (sn * nb - so * own) : -so * own;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < N2; r++) {
+    double acc = x[r];
+#pragma unroll
+    for (int q = 0; q < NM; q++) acc = fma(Gt[((long)r * NM + q) * G.nc + c], d[q], acc);
+    out[(long)c * N2 + r] = acc;
+  }
+}
+
 // Passive tracer transport on a general triangulation (common.py:110-129; k_tracer_adv of the structured engine):
 //   out_i = int_K q (grad chi_i . u + chi_i div u) - sum_{interior e} int_e chi_i (un_K q_K - un_K' q_K'),
 //   un_K = (u.n_K + |u.n_K|)/2, un_K' = (|u.n_K| - u.n_K)/2; u is continuous, so it is taken from this cell.
