@@ -2171,17 +2171,24 @@ struct Engine {
     rho = std::sqrt((double)std::max(r2, 0.0L));
     return rank;
   }
+  std::vector<double*> aug_u, aug_c;  // augmentation pairs (u, B u) of the s-step cycles (allocated on first use)
   int sstep_mr(const double* qstar, double gamma, int didx, const double* b, double* x, double rtol, double beta0, double cur0) {
     FlowScope flow_(*this);
     flow_fixed_Q(qstar);
     flow_fixed_Q(b);
     static const int smax_env = std::getenv("HDG_SSTEP_MAX") ? std::atoi(std::getenv("HDG_SSTEP_MAX")) : 6;
     static const double per_decade = std::getenv("HDG_SSTEP_PER_DECADE") ? std::atof(std::getenv("HDG_SSTEP_PER_DECADE")) : 1.7;
-    const int smax = std::max(2, std::min(std::min(smax_env, HDG_SSTEP_MAXV - 1), (int)gm_V.size() - 1));
+    // LGMRES-type augmentation: the next cycle's least-squares space also holds the last NA corrections u_j = x_{j+1} - x_j,
+    // whose images B u_j = r_j - r_{j+1} are known without an operator application (by-products of the update pass)
+    // (measured: no gain -- C3 15.55 -> 15.57 iterations, k = 4 at 512^2 25.2 -> 24.7, each cycle two vector passes dearer: off by
+    //  default, HDG_SSTEP_AUG = 1 | 2 switches it on)
+    static const int NA = std::max(0, std::min(2, std::getenv("HDG_SSTEP_AUG") ? std::atoi(std::getenv("HDG_SSTEP_AUG")) : 0));
+    const int smax = std::max(2, std::min(std::min(smax_env, HDG_SSTEP_MAXV - 1 - NA), (int)gm_V.size() - 1));
     if (!d_gram) {
       d_gram = dalloc(64);
       HIPCHECK(hipHostMalloc((void**)&h_gram, sizeof(double) * 64));
     }
+    while ((int)aug_u.size() < NA) { aug_u.push_back(dalloc(NQ)); aug_c.push_back(dalloc(NQ)); }
     double* t = wQ2;
     const RowMask mk = mask_for(KQ);
     const double target = rtol * beta0;
@@ -2189,7 +2196,7 @@ struct Engine {
     auto length_for = [&](double from) {  // iterations for the reduction from -> target at GMRES's observed tail rate
       return (int)std::ceil(per_decade * std::log10(std::max(from / target, 1.0)));
     };
-    int its = 0, weak = 0;
+    int its = 0, weak = 0, na = 0, newest = -1;  // na pairs in use; `newest`: slot of the most recent one
     double cur = cur0;
     bool have_r = false;
     while (true) {
@@ -2202,6 +2209,8 @@ struct Engine {
       std::vector<long double> G, yv;
       int nv = 0, rank = 0;
       double k0n = 0.0, rho = 0.0;
+      // order of the augmentation pairs in the least-squares problem: newest first (the truncation keeps a prefix)
+      int aslot[2] = {newest, 1 - newest};
       while (true) {
         for (int i = built + 1; i <= want; i++) {
           adv_apply(gm_V[i - 1], qstar, t, gamma);
@@ -2209,16 +2218,16 @@ struct Engine {
           its++;
         }
         built = want;
-        nv = built + 1;
+        nv = built + 1 + na;  // K_0 .. K_built, then the images c_j of the augmentation vectors
         const int npair = nv * (nv + 1) / 2;
         const int nb = std::min(std::min(dot_blocks, vec_blocks(NQ)), (dot_blocks * MAXV) / npair);
         tally(LC_DOT, bQ() * nv);
         tally(LC_OTHER, 0.0);
-        // two instantiations: up to 7 vectors (s <= 6, the default: 28 accumulators, 3 waves / SIMD) and up to 9 (244 VGPRs)
+        // two instantiations: up to 7 vectors (28 accumulators, 3 waves / SIMD) and up to 9 (244 VGPRs)
         auto gram = [&](auto tag) {
           constexpr int NV = decltype(tag)::value;
           VecList<NV> vl;
-          for (int q = 0; q < NV; q++) vl.p[q] = q < nv ? gm_V[q] : nullptr;
+          for (int q = 0; q < NV; q++) vl.p[q] = q <= built ? gm_V[q] : (q < nv ? aug_c[aslot[q - built - 1]] : nullptr);
           if (big(NQ)) k_gram<NV, true><<<nb, HDG_DOT_BLOCK, 0, stream>>>(NQ, vl, nv, d_part, mk);
           else k_gram<NV, false><<<nb, HDG_DOT_BLOCK, 0, stream>>>(NQ, vl, nv, d_part, mk);
         };
@@ -2238,31 +2247,47 @@ struct Engine {
         if (!(g00 == g00)) throw NotConverged{"s-step cycle: NaN residual"};
         k0n = std::sqrt(std::max(g00, 0.0));
         if (k0n <= target || k0n == 0.0) return its;  // the iterate the cycle started from had converged already
-        rank = sstep_ls(G, nv, built, yv, rho);
-        if (debug_on()) fprintf(stderr, "[sstep]   basis of %d (rank %d): |Mr|/|Mr0| %.3e, predicted %.3e\n", built, rank, k0n / beta0, rho / beta0);
+        rank = sstep_ls(G, nv, nv - 1, yv, rho);
+        if (debug_on()) fprintf(stderr, "[sstep]   basis of %d + %d (rank %d): |Mr|/|Mr0| %.3e, predicted %.3e\n", built, na, rank, k0n / beta0, rho / beta0);
         // enough (with a margin for the accuracy of the prediction), rank deficient, or no room left: take the step
         if (rho <= 0.7 * target || rank < built || built >= smax) break;
         want = std::min(smax, built + std::max(1, length_for(rho / 0.7)));
       }
       n_sstep_cycles++;
+      // update list: K_0 .. K_built, c_1 .. c_na, u_1 .. u_na
+      const int nvu = built + 1 + 2 * na;
       Coefs cx, cr;
       for (int i = 0; i < 32; i++) cx.c[i] = cr.c[i] = 0.0;
       cr.c[0] = 1.0;
-      for (int i = 0; i < rank; i++) { cx.c[i] = (double)yv[i]; cr.c[i + 1] = -(double)yv[i]; }
-      tally(LC_VEC, bQ() * (nv + 3));
+      for (int i = 0; i < std::min(rank, built); i++) { cx.c[i] = (double)yv[i]; cr.c[i + 1] = -(double)yv[i]; }
+      for (int j = 0; j < na; j++)
+        if (built + j < rank) { cr.c[built + 1 + j] = -(double)yv[built + j]; cx.c[built + 1 + na + j] = (double)yv[built + j]; }
+      tally(LC_VEC, bQ() * (nvu + 3 + (NA > 0 ? 2 : 0)));
       tally(LC_OTHER, 0.0);
+      // the new pair goes to a free slot, or replaces the oldest one (elementwise in place: a thread reads before it writes)
+      int slot = -1;
+      if (NA > 0) slot = na < NA ? na : aslot[na - 1];
       {
         const int nb = std::min(dot_blocks, vec_blocks(NQ));
-        VecList<HDG_SSTEP_MAXV> vl;
-        for (int q = 0; q < HDG_SSTEP_MAXV; q++) vl.p[q] = q < nv ? gm_V[q] : nullptr;
-        if (big(NQ)) k_sstep_update<HDG_SSTEP_MAXV, true><<<nb, HDG_DOT_BLOCK, 0, stream>>>(NQ, x, gm_V[0], vl, nv, cx, cr, d_part, mk);
-        else k_sstep_update<HDG_SSTEP_MAXV, false><<<nb, HDG_DOT_BLOCK, 0, stream>>>(NQ, x, gm_V[0], vl, nv, cx, cr, d_part, mk);
+        VecList<HDG_SSTEP_MAXU> vl;
+        for (int q = 0; q < HDG_SSTEP_MAXU; q++) {
+          if (q <= built) vl.p[q] = gm_V[q];
+          else if (q < built + 1 + na) vl.p[q] = aug_c[aslot[q - built - 1]];
+          else if (q < nvu) vl.p[q] = aug_u[aslot[q - built - 1 - na]];
+          else vl.p[q] = nullptr;
+        }
+        double* uo = slot >= 0 ? aug_u[slot] : nullptr;
+        double* co = slot >= 0 ? aug_c[slot] : nullptr;
+        if (big(NQ)) k_sstep_update<HDG_SSTEP_MAXU, true><<<nb, HDG_DOT_BLOCK, 0, stream>>>(NQ, x, gm_V[0], vl, nvu, cx, cr, d_part, mk, uo, co);
+        else k_sstep_update<HDG_SSTEP_MAXU, false><<<nb, HDG_DOT_BLOCK, 0, stream>>>(NQ, x, gm_V[0], vl, nvu, cx, cr, d_part, mk, uo, co);
         int dmin = fl.get(x);
-        for (int l = 0; l < nv; l++) dmin = std::min(dmin, fl.get(basis_key(l)));
+        for (int l = 0; l <= built; l++) dmin = std::min(dmin, fl.get(basis_key(l)));
+        if (na > 0) dmin = 0;
         fl.set(x, dmin);
         fl.set(basis_key(0), dmin);
         k_reduce_parts<<<1, 256, 0, stream>>>(nb, 1, d_part, d_gram, direct ? h_gram : nullptr);
       }
+      if (slot >= 0) { newest = slot; na = std::min(na + 1, NA); }
       comm->allreduce_sum(d_gram, 1, stream);
       n_reduce++;
       if (!direct) HIPCHECK(hipMemcpyAsync(h_gram, d_gram, sizeof(double), hipMemcpyDeviceToHost, stream));
@@ -2270,7 +2295,7 @@ struct Engine {
       const double rn = std::sqrt(std::max(h_gram[0], 0.0));
       if (!(rn == rn)) throw NotConverged{"s-step cycle: NaN residual"};
       if (debug_on())
-        fprintf(stderr, "[sstep] cycle of %d (rank %d): |Mr|/|Mr0| %.3e -> %.3e (predicted %.3e)\n", built, rank, k0n / beta0, rn / beta0, rho / beta0);
+        fprintf(stderr, "[sstep] cycle of %d + %d (rank %d): |Mr|/|Mr0| %.3e -> %.3e (predicted %.3e)\n", built, nv - built - 1, rank, k0n / beta0, rn / beta0, rho / beta0);
       if (rn <= target) return its;
       if (its >= cfg.tent_maxit) throw NotConverged{"tentative-velocity s-step iteration reached max iterations"};
       weak = (rn > 0.5 * k0n) ? weak + 1 : 0;

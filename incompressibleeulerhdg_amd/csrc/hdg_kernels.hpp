@@ -2543,11 +2543,15 @@ __global__ __launch_bounds__(HDG_DOT_BLOCK) void k_gram(long N, const VecList<NV
     }
   }
 }
-// x += sum_{k<nv-1} cx[k] K_k;  K_0 <- sum_{k<nv} cr[k] K_k (the new preconditioned residual; whole arrays, ghost rows follow);
-// part[block] = the block's share of |new K_0|^2 over the owned entries
+// x += sum_{k<nv} cx[k] V_k;  V_0 <- sum_{k<nv} cr[k] V_k (the new preconditioned residual; whole arrays, ghost rows follow);
+// part[block] = the block's share of |new V_0|^2 over the owned entries.  u_out / c_out (may be null, may alias a V_k): the
+// correction just applied, x_new - x_old, and its image B (x_new - x_old) = V_0_old - V_0_new -- the pair the next cycle is
+// augmented with (LGMRES: the error approximation of a cycle carries the information a restart throws away).
+#define HDG_SSTEP_MAXU 11
 template <int NV, bool NT>
 __global__ __launch_bounds__(HDG_DOT_BLOCK) void k_sstep_update(long N, double* __restrict__ x, double* __restrict__ k0, const VecList<NV> K, int nv,
-                                                                Coefs cx, Coefs cr, double* __restrict__ part, RowMask mk) {
+                                                                Coefs cx, Coefs cr, double* __restrict__ part, RowMask mk,
+                                                                double* u_out = nullptr, double* c_out = nullptr) {
   __shared__ double sm[HDG_DOT_BLOCK / 64];
   double acc = 0.0;
   HDG_VEC_PROLOGUE
@@ -2562,28 +2566,35 @@ __global__ __launch_bounds__(HDG_DOT_BLOCK) void k_sstep_update(long N, double* 
     v[0] = ldv<NT>(k0, i);
 #pragma unroll
     for (int k = 1; k < NV; k++) v[k] = (k < nv) ? ldv<NT>(K.p[k], i) : hdg_d2{0.0, 0.0};
-    hdg_d2 xv = ldv<NT>(x, i), r = hdg_d2{0.0, 0.0};
+    hdg_d2 r = hdg_d2{0.0, 0.0}, du = hdg_d2{0.0, 0.0};
 #pragma unroll
     for (int k = 0; k < NV; k++) {
       if (k < nv) {
         r = fma2(cr.c[k], v[k], r);
-        if (k < nv - 1) xv = fma2(cx.c[k], v[k], xv);
+        du = fma2(cx.c[k], v[k], du);
       }
     }
-    stv<NT>(x, i, xv);
+    const hdg_d2 xo = ldv<NT>(x, i);
+    stv<NT>(x, i, hdg_d2{xo.x + du.x, xo.y + du.y});
     stv<NT>(k0, i, r);
+    if (u_out) {
+      stv<NT>(u_out, i, du);
+      stv<NT>(c_out, i, hdg_d2{v[0].x - r.x, v[0].y - r.y});
+    }
     acc = fma(m1 * r.y, r.y, fma(m0 * r.x, r.x, acc));
   }
   if (tail_) {
     const double mf = mk.w_ > 0 ? row_factor(mk, N, it_) : 1.0;
-    double xv = x[it_], r = 0.0;
+    double du = 0.0, r = 0.0;
+    const double v0 = k0[it_];
     for (int k = 0; k < nv; k++) {
-      const double vk = k == 0 ? k0[it_] : K.p[k][it_];
+      const double vk = k == 0 ? v0 : K.p[k][it_];
       r = fma(cr.c[k], vk, r);
-      if (k < nv - 1) xv = fma(cx.c[k], vk, xv);
+      du = fma(cx.c[k], vk, du);
     }
-    x[it_] = xv;
+    x[it_] += du;
     k0[it_] = r;
+    if (u_out) { u_out[it_] = du; c_out[it_] = v0 - r; }
     acc = fma(mf * r, r, acc);
   }
   const int lane = threadIdx.x & 63, wv_ = threadIdx.x >> 6;
