@@ -578,6 +578,13 @@ def main():
                 cb["gpu_same_size"] = gpu_at_size(nxs, k, args, kappa)
             cb["gpu_over_cpu_same_size"] = cb["gpu_same_size"]["value"] / cb["value"]
             cb["reassembly_split"] = reassembly_split(eng, k, nx, cb, elapsed / args.steps)
+            # what the twin moves, priced against ITS memory system: the engine's algorithmic bytes per step (launch census of
+            # the timed GPU steps: same discretisation, same stage structure; the twin's GMRES(8) / PCG make at least as many
+            # vector passes, so this is a LOWER bound on its traffic) over the twin's seconds per step, next to the host's triad
+            if nxs == nx and "timestep" in cb.get("timers", {}):
+                gbs_cpu = tot_bytes / args.steps / 1e9 / (cb["timers"]["timestep"]["avg_ms"] * 1e-3)
+                cb["algorithmic_GBs_lower_bound"] = gbs_cpu
+                cb["fraction_of_host_triad"] = gbs_cpu / cb["host_stream_triad_GBs"] if cb.get("host_stream_triad_GBs") else None
             line["cpu_baseline"] = cb
         print(json.dumps(line))
     if dist is not None:

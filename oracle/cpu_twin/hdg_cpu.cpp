@@ -444,8 +444,74 @@ struct Twin {
       for (int m = 0; m < NL; m++) l[e * NL + m] = src[m];
     }
   }
+  // out = (-S) lam, lane-blocked (round 4: the condensed solve was the unfused scalar half of the twin, 51 % of its step): a row of
+  // squares at a time, W cells per AVX-512 lane block; the products S_K lam_K of both cells of a square go to a row buffer in
+  // structure-of-arrays order, the edges of the row are then assembled from the (at most two) cell contributions; the e0
+  // contribution of the row below is recomputed (NL of the NT rows of S_U) so that rows stay independent (OpenMP over rows).
+  template <int KK>
+  void trace_apply_simd(const vec& lam, vec& out) const {
+    constexpr int NL_ = KK + 1, NT_ = 3 * NL_;
+    const double *SL = T->SK[0].data(), *SU = T->SK[1].data();
+    const int nxp = ((nx + W - 1) / W) * W;
+#pragma omp parallel
+    {
+      std::vector<double> yL((size_t)NT_ * nxp), yU((size_t)NT_ * nxp), yB((size_t)NL_ * nxp);
+#pragma omp for schedule(static)
+      for (int j = 0; j <= ny; j++) {
+        // products of the cells of row j (L and U) and the e0 rows of U(., j-1)
+        for (int i0 = 0; i0 < nx; i0 += W) {
+          const int w = std::min(W, nx - i0);
+          alignas(64) double l[NT_][W];
+          auto gather = [&](int sh, int jj) {
+            for (int e = 0; e < 3; e++)
+              for (int q = 0; q < W; q++) {
+                const double* src = &lam[edge_of(sh, e, i0 + std::min(q, w - 1), jj) * NL_];
+                for (int m = 0; m < NL_; m++) l[e * NL_ + m][q] = src[m];
+              }
+          };
+          auto product = [&](const double* S, int r0, int nr, double* dst) {  // dst[(r - r0) * nxp + i] = -(S l)_r
+            for (int r = r0; r < r0 + nr; r++) {
+              alignas(64) double acc[W] = {0};
+              for (int c = 0; c < NT_; c++) {
+                const double sv = S[r * NT_ + c];
+#pragma omp simd
+                for (int q = 0; q < W; q++) acc[q] -= sv * l[c][q];
+              }
+#pragma omp simd
+              for (int q = 0; q < W; q++) dst[(size_t)(r - r0) * nxp + i0 + q] = acc[q];
+            }
+          };
+          if (j < ny) {
+            gather(0, j); product(SL, 0, NT_, yL.data());
+            gather(1, j); product(SU, 0, NT_, yU.data());
+          }
+          if (j > 0) { gather(1, j - 1); product(SU, 0, NL_, yB.data()); }
+        }
+        // edges of row j: H(i, j) = L(i, j) e0 + U(i, j-1) e0;  D(i, j) = L e1 + U e1;  V(i, j) = L(i, j) e2 + U(i-1, j) e2
+        for (int i = 0; i < nx; i++)
+          for (int m = 0; m < NL_; m++)
+            out[eH(i, j) * NL_ + m] = (j < ny ? yL[(size_t)m * nxp + i] : 0.0) + (j > 0 ? yB[(size_t)m * nxp + i] : 0.0);
+        if (j < ny) {
+          for (int i = 0; i < nx; i++)
+            for (int m = 0; m < NL_; m++)
+              out[eD(i, j) * NL_ + m] = yL[(size_t)(NL_ + m) * nxp + i] + yU[(size_t)(NL_ + m) * nxp + i];
+          for (int i = 0; i <= nx; i++)
+            for (int m = 0; m < NL_; m++)
+              out[eV(i, j) * NL_ + m] = (i < nx ? yL[(size_t)(2 * NL_ + m) * nxp + i] : 0.0) + (i > 0 ? yU[(size_t)(2 * NL_ + m) * nxp + i - 1] : 0.0);
+        }
+      }
+    }
+  }
   // out = (-S) lam
   void trace_apply(const vec& lam, vec& out) const {
+    if (use_simd()) {
+      switch (K) {
+        case 1: trace_apply_simd<1>(lam, out); return;
+        case 2: trace_apply_simd<2>(lam, out); return;
+        case 3: trace_apply_simd<3>(lam, out); return;
+        default: trace_apply_simd<4>(lam, out); return;
+      }
+    }
     for_edges([&](long ed, int, int, long cL, int e, long cU) {
       double y[8], l[24];
       for (int m = 0; m < NL; m++) y[m] = 0.0;

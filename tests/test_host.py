@@ -330,3 +330,52 @@ def test_general_mesh_host_side_invariants(tmp_path, k, level):
     p = k + 1
     assert int(v["ncg"]) == int(v["nv"]) + int(v["ne"]) * (p - 1) + int(v["nc"]) * (p - 1) * (p - 2) // 2
     assert abs(f("cg_volume") - m.volume) < 1e-11
+
+
+def test_unit_disk_mesh_numbering_independent_invariants():
+    """UnitDiskMesh (driver.py:184-185) is restated from memory of Firedrake's utility mesh on both the product and the
+    oracle side -- no reference fixture covers its numbering or coordinates (parity unpinned).  What any correct
+    construction must satisfy, whatever its numbering: 8 * 4^L cells, Euler's formula for a disk, every boundary vertex on
+    the unit circle and none of the interior ones, positively oriented non-degenerate cells, an area that tends to pi at second
+    order, and the same vertex / cell counts and area from the oracle's independent construction."""
+    import numpy as np
+
+    from incompressibleeulerhdg_amd.mesh import UnitDiskMesh
+    from oracle import fem
+
+    prev_err = None
+    for level in range(0, 6):
+        m = UnitDiskMesh(level)
+        X, C = np.asarray(m.vertices), np.asarray(m.cells)
+        nc = 8 * 4**level
+        assert C.shape == (nc, 3) and len(np.unique(C)) == len(X)
+        # edges: interior ones are shared by two cells, boundary ones by one
+        E = np.sort(np.concatenate([C[:, [0, 1]], C[:, [1, 2]], C[:, [2, 0]]]), axis=1)
+        uniq, counts = np.unique(E, axis=0, return_counts=True)
+        assert set(counts) <= {1, 2}
+        nb = int(np.sum(counts == 1))
+        assert nb == 8 * 2**level                      # boundary edges = boundary vertices of a disk
+        assert len(X) - len(uniq) + nc == 1            # Euler characteristic of a disk
+        bverts = np.unique(uniq[counts == 1])
+        r = np.linalg.norm(X, axis=1)
+        assert len(bverts) == nb and np.allclose(r[bverts], 1.0, atol=1e-14)
+        interior = np.setdiff1d(np.arange(len(X)), bverts)
+        assert np.all(r[interior] < 1.0 - 1e-9)
+        a, b, c = X[C[:, 0]], X[C[:, 1]], X[C[:, 2]]
+        area2 = (b[:, 0] - a[:, 0]) * (c[:, 1] - a[:, 1]) - (b[:, 1] - a[:, 1]) * (c[:, 0] - a[:, 0])
+        assert np.all(np.abs(area2) > 1e-12)
+        area = 0.5 * np.sum(np.abs(area2))
+        err = np.pi - area                             # inscribed polygon: below pi, second order in h
+        assert err > 0
+        if prev_err is not None and level >= 2:
+            assert 3.0 < prev_err / err < 5.0, (level, prev_err / err)
+        prev_err = err
+        # the oracle's independent construction: same counts and area (the numbering may differ)
+        o = fem.unit_disk_mesh(level)
+        if o is not None:
+            oX, oC = np.asarray(o.vertices), np.asarray(o.cells)
+            assert oC.shape == C.shape and oX.shape == X.shape
+            oa, ob, oc = oX[oC[:, 0]], oX[oC[:, 1]], oX[oC[:, 2]]
+            oarea = 0.5 * np.sum(np.abs((ob[:, 0] - oa[:, 0]) * (oc[:, 1] - oa[:, 1]) - (ob[:, 1] - oa[:, 1]) * (oc[:, 0] - oa[:, 0])))
+            assert abs(oarea - area) < 1e-12
+    assert prev_err < 2e-3
