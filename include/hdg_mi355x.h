@@ -183,8 +183,10 @@ int hdg_get_iteration_stats(hdg_handle* h, double* sums, long* counts, int reset
  * silent".  The single-reduction CG of this library replaces its residual by the true one (r = b - T x, recurrences
  * restarted) when the recurrence residual stalls within three decades of the target or p.Ap turns non-positive, and ends
  * a solve only if the TRUE preconditioned residual meets rtol or lies at its rounding floor 32 eps |x|:
- *   events[0] residual replacements, events[1] solves ended at the rounding floor, events[2..3] reserved (0).
- * A third symptom within one solve returns HDG_ERR_NOT_CONVERGED. */
+ *   events[0] residual replacements, events[1] solves ended at the rounding floor.
+ * A third confirmed drift within one solve returns HDG_ERR_NOT_CONVERGED.
+ * Tentative-velocity solves (hdg_imex.py:223-228: GMRES rtol 1e-10): events[2] s-step minimal-residual cycles taken by the tail
+ * of the Chebyshev iteration, events[3] solves that two weak cycles in a row handed on to GMRES (which errors at its limit). */
 #define HDG_N_SOLVER_EVENTS 4
 int hdg_get_solver_events(hdg_handle* h, long* events, int reset);
 

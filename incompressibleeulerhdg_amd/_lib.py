@@ -374,7 +374,8 @@ class Engine:
         """Residual replacements / rounding-floor exits of the condensed solves since the last reset (dict)."""
         ev = np.zeros(4, dtype=np.int64)
         self._ck(self.lib.hdg_get_solver_events(self.h, ev.ctypes.data_as(_lp), 1 if reset else 0))
-        return {"cg_residual_replacements": int(ev[0]), "cg_floor_exits": int(ev[1])}
+        return {"cg_residual_replacements": int(ev[0]), "cg_floor_exits": int(ev[1]), "sstep_cycles": int(ev[2]),
+                "sstep_gmres_fallbacks": int(ev[3])}
 
     def kernel_forms(self):
         """Which form of its kernels the engine launches (hdg_get_kernel_forms): dict of small integers."""

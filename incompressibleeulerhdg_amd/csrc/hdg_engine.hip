@@ -2671,7 +2671,7 @@ struct Engine {
   }
   void run_vcycle() { if (periodic) vcycle_periodic(0); else vcycle(0); }
   // Dense form of the V-cycle tail (k_p1_dense_tail): column c of M = the tail kernel applied to the c-th unit vector.
-  // Built once per engine (~1100 launches of the one-workgroup kernel, ~40 ms); HDG_MG_NO_DENSE_TAIL keeps the tail kernel.
+  // Built once per engine (one launch: a workgroup per unit vector); HDG_MG_NO_DENSE_TAIL keeps the tail kernel.
   double* tail_M = nullptr;
   int tail_lev = -1, tail_pitch = 0;
   void build_dense_tail() {
@@ -2686,17 +2686,17 @@ struct Engine {
     const int N = (mg_n[lev] + 1) * (mg_n[lev] + 1), pitch = (N + 1) & ~1;
     double* MT = dalloc((long)N * pitch);
     double* M = dalloc((long)N * pitch);
-    zero(mg_b[lev], N);
-    for (int c = 0; c < N; c++) {
-      k_fill<<<1, 1, 0, stream>>>(1, mg_b[lev] + c, 1.0);
-      vcycle(lev);  // tail_M is still null: the tail kernel
-      HIPCHECK(hipMemcpyAsync(MT + (long)c * pitch, mg_x[lev], sizeof(double) * N, hipMemcpyDeviceToDevice, stream));
-      k_fill<<<1, 1, 0, stream>>>(1, mg_b[lev] + c, 0.0);
+    {
+      // every column in one launch: workgroup c applies the tail kernel to the c-th unit vector
+      static const int nsw = std::getenv("HDG_MG_SWEEPS") ? std::atoi(std::getenv("HDG_MG_SWEEPS")) : 2;
+      static const int ncoarse = std::getenv("HDG_MG_COARSE") ? std::atoi(std::getenv("HDG_MG_COARSE")) : 2;
+      P1Tail tl;
+      tl.nlev = 0;
+      for (int l = lev; l < (int)mg_n.size(); l++) tl.n[tl.nlev++] = mg_n[l];
+      k_p1_vcycle_tail<<<N, 1024, 0, stream>>>(tl, nullptr, MT, nsw, ncoarse, pitch);
     }
     k_transpose_sq<<<dim3((N + 255) / 256, N), 256, 0, stream>>>(N, pitch, MT, M);
     HIPCHECK(hipStreamSynchronize(stream));
-    lc_calls[LC_MG] -= N; lc_bytes[LC_MG] -= 16.0 * tot * N;  // set-up launches are not part of the census
-    lc_calls[LC_COPY] -= 1; lc_bytes[LC_COPY] -= bvec((long)N);
     HIPCHECK(hipFree(MT));
     allocs.erase(std::find(allocs.begin(), allocs.end(), (void*)MT));
     tail_M = M; tail_lev = lev; tail_pitch = pitch;
@@ -4194,8 +4194,8 @@ int hdg_get_iteration_stats(hdg_handle* h, double* sums, long* counts, int reset
 }
 int hdg_get_solver_events(hdg_handle* h, long* events, int reset) {
   HDG_API_BEGIN(h)
-  if (events) { events[0] = E.ev_cg_replacements; events[1] = E.ev_cg_floor_exits; events[2] = 0; events[3] = 0; }
-  if (reset) { E.ev_cg_replacements = 0; E.ev_cg_floor_exits = 0; }
+  if (events) { events[0] = E.ev_cg_replacements; events[1] = E.ev_cg_floor_exits; events[2] = E.n_sstep_cycles; events[3] = E.n_sstep_fallbacks; }
+  if (reset) { E.ev_cg_replacements = 0; E.ev_cg_floor_exits = 0; E.n_sstep_cycles = 0; E.n_sstep_fallbacks = 0; }
   HDG_API_END(h)
 }
 int hdg_get_kernel_forms(hdg_handle* h, int* forms) {

@@ -2937,14 +2937,21 @@ __device__ __forceinline__ double p1_res_lds(const double* x, const double* b, i
   return b[j * (n + 1) + i] - (diag * x[j * (n + 1) + i] - off);
 }
 #define HDG_P1_TAIL_MAX 1600
+// unit_pitch > 0 (set-up of the dense form, k_p1_dense_tail): workgroup c solves for the c-th UNIT right-hand side and writes its
+// result to x_out + c * unit_pitch -- every column of the tail's matrix in ONE launch
 __global__ __launch_bounds__(1024) void k_p1_vcycle_tail(P1Tail tl, const double* __restrict__ b_in,
-                                                          double* __restrict__ x_out, int nsw, int ncoarse) {
+                                                          double* __restrict__ x_out, int nsw, int ncoarse, int unit_pitch = 0) {
   __shared__ double X[HDG_P1_TAIL_MAX];
   __shared__ double B[HDG_P1_TAIL_MAX];
   int offs[9];
   offs[0] = 0;
   for (int l = 0; l < tl.nlev; l++) offs[l + 1] = offs[l] + (tl.n[l] + 1) * (tl.n[l] + 1);
-  for (int p = threadIdx.x; p < offs[1]; p += blockDim.x) B[p] = b_in[p];
+  if (unit_pitch > 0) {
+    for (int p = threadIdx.x; p < offs[1]; p += blockDim.x) B[p] = p == (int)blockIdx.x ? 1.0 : 0.0;
+    x_out += (long)blockIdx.x * unit_pitch;
+  } else {
+    for (int p = threadIdx.x; p < offs[1]; p += blockDim.x) B[p] = b_in[p];
+  }
   for (int p = threadIdx.x; p < offs[tl.nlev]; p += blockDim.x) X[p] = 0.0;
   __syncthreads();
   for (int l = 0; l < tl.nlev - 1; l++) {

@@ -282,7 +282,8 @@ def test_bench_line_contract(hip_lib):
         assert d["timers"]["timestep"]["ncall"] == 2
         # round 4: residual replacements / floor exits of the condensed solves in the timed steps (none on a healthy run) and the
         # kernel forms as the engine reports them
-        assert d["config"]["solver_events"] == {"cg_residual_replacements": 0, "cg_floor_exits": 0}
+        ev = d["config"]["solver_events"]
+        assert ev["cg_residual_replacements"] == 0 and ev["cg_floor_exits"] == 0 and ev["sstep_gmres_fallbacks"] == 0 and ev["sstep_cycles"] >= 0
         assert d["config"]["kernel_forms"]["lift"] == (0 if k <= 2 else 2) and d["config"]["kernel_forms"]["trace_precond"] == 1
         assert "alt_stop_rule" not in d  # opt-in only (BENCH_ALT_STOP=1)
 

@@ -41,7 +41,7 @@ def test_default_runs_need_no_replacement(hip_lib):
     for a, b in zip(got, ref):
         assert _rel(a, b) < TOL
     ev = ts._engine.solver_events()
-    assert ev == {"cg_residual_replacements": 0, "cg_floor_exits": 0}, ev
+    assert ev["cg_residual_replacements"] == 0 and ev["cg_floor_exits"] == 0 and ev["sstep_gmres_fallbacks"] == 0, ev
 
 
 @pytest.mark.parametrize("k,nx,at", [(1, 8, 3), (2, 8, 5), (3, 4, 2)])
