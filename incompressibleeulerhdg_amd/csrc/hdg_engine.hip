@@ -546,7 +546,10 @@ struct Engine {
     g.nyc = g.ny + (comm->rank == comm->size - 1 ? 1 : 0);
     periodic = c.periodic != 0;
     Ldom = c.length > 0 ? c.length : 1.0;
-    overlap_on = !std::getenv("HDG_NO_OVERLAP") && (std::strcmp(comm->name(), "rccl") == 0 || std::getenv("HDG_OVERLAP") != nullptr);
+    // interior / boundary split around halo exchanges on a second stream: OPT-IN (HDG_OVERLAP=1) since round 4 -- the logic is
+    // tested on every multi-rank test over the shared-memory transport, but ncclSend / ncclRecv on a second stream beside
+    // kernels has never run on two devices (round-3 advisor finding): the first multi-GPU run uses the plain single-stream order
+    overlap_on = !std::getenv("HDG_NO_OVERLAP") && std::getenv("HDG_OVERLAP") != nullptr;
     if (periodic && comm->size > 1) throw std::string("the periodic mesh is implemented for a single rank");
     if (periodic && (c.nx % 2 != 0)) throw std::string("the periodic mesh needs an even nx (red-black coarse-grid sweeps)");
     if (periodic && g.ny < 4) throw std::string("the periodic mesh needs at least 4 cell rows");
@@ -919,10 +922,9 @@ struct Engine {
   static Geo corner_gap(Geo c, const Geo& full, int lo, int hi) { c.wgapn = full.nyc - lo - hi; return c; }
   hipStream_t cstream = nullptr;               // communication stream (exchanges that overlap with interior launches)
   hipEvent_t ev_in = nullptr, ev_halo = nullptr;
-  // On by default over RCCL (device-side send / recv: nothing blocks the host).  Off by default over the host-staged
-  // shared-memory transport: that one exists for ranks SHARING a device, where the interior launch occupies the very GPU the
-  // peer needs for its pack kernel (C3 rehearsal, 2 ranks on one MI355X: 226 ms/step with the split, 178 without).
-  // HDG_OVERLAP=1 forces it on (the multi-rank tests, which run over shared memory), HDG_NO_OVERLAP=1 off.
+  // Opt-in (HDG_OVERLAP=1; every multi-rank test sets it): over RCCL it has never run on two devices; over the host-staged
+  // shared-memory transport (ranks SHARING a device) the interior launch occupies the very GPU the peer needs for its pack
+  // kernel (C3 rehearsal, 2 ranks on one MI355X: 226 ms/step with the split, 178 without).  HDG_NO_OVERLAP=1 forbids it.
   bool overlap_on = false;
   long n_overlapped = 0;                        // exchanges that ran beside an interior launch (census)
   // the deferred exchange of stencil_in(): runs on the communication stream after everything queued on the compute stream
