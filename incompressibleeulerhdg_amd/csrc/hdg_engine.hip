@@ -1955,6 +1955,14 @@ struct Engine {
   int gmres(const double* qstar, double gamma, int didx, const double* b, double* x, double rtol = -1.0,
             int maxit = -1, bool strict = true, std::vector<std::complex<double>>* ritz = nullptr, int m_cycle = 0,
             double* beta_first = nullptr, double* beta_last = nullptr, double beta0_given = -1.0, int first_cycle = 4) {
+    // Round 4: a WHOLE strict solve (the fully implicit stepper at k >= 2, wide-ellipse stages that the Chebyshev iteration
+    // declines, general meshes at k = 1) runs as s-step minimal-residual cycles -- the same Krylov spaces as GMRES(6) without the
+    // Gram-Schmidt passes, which cost more than the operator (sstep_mr; two weak cycles come back here in Arnoldi form).  The
+    // Arnoldi form stays for the Ritz estimate, the inexact inner solves of the monolithic preconditioner, the fall-backs after a
+    // growing / stalled Chebyshev iteration, single-precision basis storage; HDG_GMRES_ARNOLDI restores it everywhere.
+    static const bool arnoldi_env = std::getenv("HDG_GMRES_ARNOLDI") != nullptr;
+    if (!arnoldi_env && !arnoldi_only && !ritz && strict && !basis_f32 && m_cycle == 0 && first_cycle == 4 && gm_V.size() >= 4)
+      return sstep_mr(qstar, gamma, didx, b, x, rtol < 0 ? cfg.tent_rtol : rtol, beta0_given, -1.0);
     FlowScope flow_(*this);
     flow_fixed_Q(qstar);
     flow_fixed_Q(b);
@@ -2133,6 +2141,7 @@ struct Engine {
   // (the cycle length is chosen from the reduction still needed: 1.7 iterations per decade + 1, GMRES's observed 5-6 for 3-4
   // decades).  Two cycles in a row that gain less than a factor 2 hand the solve to GMRES (which throws at its iteration limit).
   long n_sstep_cycles = 0, n_sstep_fallbacks = 0;
+  bool arnoldi_only = false;  // set while a fall-back of the s-step cycles runs
   double *d_gram = nullptr, *h_gram = nullptr;
   // least-squares coefficients of min |K_0 - sum_{i=1..sl} y_i K_i| from the Gram matrix G ((sl+1) x (sl+1), row-major):
   // scaled normal equations, Cholesky in long double truncated at the first pivot below 1e-13; returns the rank and the
@@ -2193,7 +2202,7 @@ struct Engine {
     while ((int)aug_u.size() < NA) { aug_u.push_back(dalloc(NQ)); aug_c.push_back(dalloc(NQ)); }
     double* t = wQ2;
     const RowMask mk = mask_for(KQ);
-    const double target = rtol * beta0;
+    double target = rtol * beta0;  // beta0 <= 0: the norm of the first residual of this call (a whole solve by s-step cycles)
     const bool direct = comm->size == 1 && direct_host();
     auto length_for = [&](double from) {  // iterations for the reduction from -> target at GMRES's observed tail rate
       return (int)std::ceil(per_decade * std::log10(std::max(from / target, 1.0)));
@@ -2248,6 +2257,7 @@ struct Engine {
         const double g00 = (double)G[0];
         if (!(g00 == g00)) throw NotConverged{"s-step cycle: NaN residual"};
         k0n = std::sqrt(std::max(g00, 0.0));
+        if (beta0 <= 0.0) { beta0 = k0n; target = rtol * beta0; if (beta0 == 0.0) return its; }
         if (k0n <= target || k0n == 0.0) return its;  // the iterate the cycle started from had converged already
         rank = sstep_ls(G, nv, nv - 1, yv, rho);
         if (debug_on()) fprintf(stderr, "[sstep]   basis of %d + %d (rank %d): |Mr|/|Mr0| %.3e, predicted %.3e\n", built, na, rank, k0n / beta0, rho / beta0);
@@ -2304,6 +2314,8 @@ struct Engine {
       if (weak >= 2 || rank == 0) {
         n_sstep_fallbacks++;
         if (debug_on()) fprintf(stderr, "[sstep] two weak cycles: GMRES takes over\n");
+        struct Guard { bool& f; ~Guard() { f = false; } } guard_{arnoldi_only};
+        arnoldi_only = true;  // the Arnoldi form (gmres() would otherwise hand a whole solve back to the s-step cycles)
         return its + gmres(qstar, gamma, didx, b, x, rtol, cfg.tent_maxit, true, nullptr, 0, nullptr, nullptr, beta0);
       }
       cur = rn;
@@ -2520,6 +2532,8 @@ struct Engine {
           // round 4: the tail as s-step minimal-residual cycles (no Gram-Schmidt passes); HDG_TAIL_GMRES restores the GMRES cycle
           static const bool tail_gmres = std::getenv("HDG_TAIL_GMRES") != nullptr;
           if (tail && !tail_gmres && !basis_f32) return its + sstep_mr(qstar, gamma, didx, b, x, rtol, beta0, nz);
+          struct Guard { bool& f; bool old; ~Guard() { f = old; } } guard_{arnoldi_only, arnoldi_only};
+          arnoldi_only = true;  // robustness path after a growing / stalled iteration: the Arnoldi form
           return its + gmres(qstar, gamma, didx, b, x, rtol, cfg.tent_maxit, true, nullptr, 0, nullptr, nullptr, beta0, tail ? hand_cycle : 4);
         }
         last = std::min(last, nz);
