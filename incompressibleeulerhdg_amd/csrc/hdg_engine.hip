@@ -339,7 +339,11 @@ struct Engine {
     const Csr P0 = p1_to_trace_matrix(*gtab, *gm);
     const Csr R0 = csr_transpose(P0);
     const Csr A0 = csr_multiply(R0, csr_multiply(S_host, P0));
-    amg_build(A0, amg_host);
+    // coarsening stops at <= 2000 vertices (round 3: 400), where the dense pseudo-inverse takes over: on the level-6 disk the
+    // hierarchy is 16 641 -> 1 893 (dense) instead of -> 1 893 -> 149 (dense) -- one smoothed level (18 launches of ~5 us per
+    // V-cycle) fewer for a 29 MB matrix-vector product; HDG_AMG_MAX_COARSE overrides
+    static const int amg_max_coarse = std::getenv("HDG_AMG_MAX_COARSE") ? std::atoi(std::getenv("HDG_AMG_MAX_COARSE")) : 2000;
+    amg_build(A0, amg_host, amg_max_coarse);
     amg.P0 = upload_csr(P0); amg.R0 = upload_csr(R0);
     for (size_t l = 0; l < amg_host.lev.size(); l++) {
       const AmgLevel& L = amg_host.lev[l];
