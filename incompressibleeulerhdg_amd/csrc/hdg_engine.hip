@@ -312,8 +312,25 @@ struct Engine {
     }
     fl.set(y, 0);
   }
+  // y = alpha A x + beta z
+  void csr3(const DevCsr& A, const double* x, double alpha, double beta, const double* z, double* y) {
+    tally(LC_OTHER, 12.0 * A.nnz + 8.0 * (A.ncols + 2.0 * A.nrows));
+    const long nthr = (long)A.nrows * A.tpr;
+    const int nblk = (int)((nthr + 255) / 256);
+    switch (A.tpr) {
+      case 1: k_csr_apply3<1><<<nblk, 256, 0, stream>>>(A, x, alpha, beta, z, y); break;
+      case 2: k_csr_apply3<2><<<nblk, 256, 0, stream>>>(A, x, alpha, beta, z, y); break;
+      case 4: k_csr_apply3<4><<<nblk, 256, 0, stream>>>(A, x, alpha, beta, z, y); break;
+      case 8: k_csr_apply3<8><<<nblk, 256, 0, stream>>>(A, x, alpha, beta, z, y); break;
+      case 16: k_csr_apply3<16><<<nblk, 256, 0, stream>>>(A, x, alpha, beta, z, y); break;
+      case 32: k_csr_apply3<32><<<nblk, 256, 0, stream>>>(A, x, alpha, beta, z, y); break;
+      default: k_csr_apply3<64><<<nblk, 256, 0, stream>>>(A, x, alpha, beta, z, y); break;
+    }
+    fl.set(y, 0);
+  }
   // P1 coarse space of the trace preconditioner on a general mesh and its algebraic hierarchy (hdg_amg.hpp)
   struct AmgDev {
+    std::vector<const double*> dinv;     // inverse diagonals as vectors (fused smoother k_amg_cheb)
     DevCsr P0, R0;                       // vertices <-> trace space
     std::vector<DevCsr> A, P, R, Dinv;   // per level (Dinv: the inverse diagonal as a matrix for the CSR kernel)
     std::vector<double*> x, b, r, d;
@@ -361,6 +378,7 @@ struct Engine {
       for (int i = 0; i < n; i++) D.col[(size_t)i] = i;
       D.val = L.dinv;
       amg.Dinv.push_back(upload_csr(D));
+      amg.dinv.push_back(upload(L.dinv));
       amg.x.push_back(dalloc(n)); amg.b.push_back(dalloc(n)); amg.r.push_back(dalloc(n)); amg.d.push_back(dalloc(n));
     }
     if (amg_host.coarse_pinv.nrows > 0) amg.Cinv = upload_csr(amg_host.coarse_pinv);
@@ -379,6 +397,30 @@ struct Engine {
     const double rn = 1.0 / (2.0 * sigma1 - rho);
     double* r = amg.r[l];
     double* d = amg.d[l];
+    static const bool unfused = std::getenv("HDG_AMG_UNFUSED") != nullptr;
+    if (!unfused) {  // two launches (k_amg_cheb) instead of six or seven
+      const DevCsr& A = amg.A[l];
+      const long nthr = (long)A.nrows * A.tpr;
+      const int nblk = (int)((nthr + 255) / 256);
+      const double* xin = zero_init ? nullptr : amg.x[l];
+      tally(LC_OTHER, 2.0 * (12.0 * A.nnz + 8.0 * 5.0 * n));
+      tally(LC_OTHER, 0.0);
+      auto run = [&](auto tt) {
+        constexpr int TT = decltype(tt)::value;
+        k_amg_cheb<TT, true><<<nblk, 256, 0, stream>>>(A, amg.dinv[l], amg.b[l], xin, r, d, nullptr, 1.0 / theta, 0.0, 0.0);
+        k_amg_cheb<TT, false><<<nblk, 256, 0, stream>>>(A, amg.dinv[l], amg.b[l], xin, r, d, amg.x[l], 0.0, rn * rho, 2.0 * rn / delta);
+      };
+      switch (A.tpr) {
+        case 1: run(std::integral_constant<int, 1>{}); break;
+        case 2: run(std::integral_constant<int, 2>{}); break;
+        case 4: run(std::integral_constant<int, 4>{}); break;
+        case 8: run(std::integral_constant<int, 8>{}); break;
+        case 16: run(std::integral_constant<int, 16>{}); break;
+        case 32: run(std::integral_constant<int, 32>{}); break;
+        default: run(std::integral_constant<int, 64>{}); break;
+      }
+      return;
+    }
     copy(r, amg.b[l], n);
     if (!zero_init) csr(amg.A[l], amg.x[l], -1.0, 1.0, r);        // r0 = b - A x
     csr(amg.Dinv[l], r, 1.0 / theta, 0.0, d);                     // d0 = Dinv r0 / theta
@@ -397,8 +439,7 @@ struct Engine {
       return;
     }
     amg_cheb(l, true);
-    copy(amg.r[l], amg.b[l], amg.n[l]);
-    csr(amg.A[l], amg.x[l], -1.0, 1.0, amg.r[l]);
+    csr3(amg.A[l], amg.x[l], -1.0, 1.0, amg.b[l], amg.r[l]);  // r = b - A x
     csr(amg.R[l], amg.r[l], 1.0, 0.0, amg.b[l + 1]);
     amg_vcycle(l + 1);
     csr(amg.P[l], amg.x[l + 1], 1.0, 1.0, amg.x[l]);

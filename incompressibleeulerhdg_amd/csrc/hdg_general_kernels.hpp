@@ -127,6 +127,57 @@ __global__ __launch_bounds__(64) void k_g_adv(GGeo G, const double* __restrict__
   }
 }
 
+// y = beta * z + alpha * A x  (z: a third vector; the residual b - A x without copying b first)
+template <int T>
+__global__ __launch_bounds__(256) void k_csr_apply3(DevCsr A, const double* __restrict__ x, double alpha, double beta,
+                                                    const double* __restrict__ z, double* __restrict__ y) {
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long r = gid / T;
+  const int lane = (int)(gid % T);
+  const bool live = r < A.nrows;
+  double acc = 0.0;
+  if (live) {
+    const int b = A.rowptr[r], e = A.rowptr[r + 1];
+    for (int q = b + lane; q < e; q += T) acc = fma(A.val[q], x[A.col[q]], acc);
+  }
+#pragma unroll
+  for (int off = T / 2; off > 0; off >>= 1) acc += __shfl_down(acc, off, T);
+  if (live && lane == 0) y[r] = fma(alpha, acc, beta * z[r]);
+}
+// Chebyshev(2) / Jacobi smoother of an algebraic multigrid level in two launches instead of six or seven (round 4: the
+// general-mesh path is launch bound, ~5 us per launch on vectors of 10^3 .. 10^4 entries):
+//   first  (FIRST = true):   r0 = b - A x  (x_in = nullptr: r0 = b),  d0 = dinv r0 / theta;  stores r0, d0
+//   second (FIRST = false):  r1 = r0 - A d0,  d1 = c1 d0 + c2 dinv r1,  x = (x_in ? x_in : 0) + d0 + d1
+// (in the second launch a row reads d0 of OTHER rows and writes x of its own row only: no hazard)
+template <int T, bool FIRST>
+__global__ __launch_bounds__(256) void k_amg_cheb(DevCsr A, const double* __restrict__ dinv, const double* __restrict__ b,
+                                                  const double* x_in, double* __restrict__ r0, double* __restrict__ d0,
+                                                  double* x_out, double inv_theta, double c1, double c2) {  // x_in may be x_out
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long r = gid / T;
+  const int lane = (int)(gid % T);
+  const bool live = r < A.nrows;
+  const double* __restrict__ v = FIRST ? x_in : d0;
+  double acc = 0.0;
+  if (live && v) {
+    const int bb = A.rowptr[r], e = A.rowptr[r + 1];
+    for (int q = bb + lane; q < e; q += T) acc = fma(A.val[q], v[A.col[q]], acc);
+  }
+#pragma unroll
+  for (int off = T / 2; off > 0; off >>= 1) acc += __shfl_down(acc, off, T);
+  if (live && lane == 0) {
+    if (FIRST) {
+      const double rr = b[r] - acc;
+      r0[r] = rr;
+      d0[r] = dinv[r] * rr * inv_theta;
+    } else {
+      const double r1 = r0[r] - acc, dd = d0[r];
+      const double d1 = fma(c1, dd, c2 * dinv[r] * r1);
+      x_out[r] = (x_in ? x_in[r] : 0.0) + dd + d1;
+    }
+  }
+}
+
 // BDM projection / hybrid two-level preconditioner on a general triangulation, MATRIX FREE (round 4; the assembled form is one
 // CSR product with 80-entry rows, 19 KB of matrix per cell at k = 2: 45 % of a Kelvin-Helmholtz step on the level-6 disk):
 //   out_K = x_K + G_K d_K,   d_K[l] = w (N_l^{K'} x_K' - N_l^K x_K)  (interior, w = 1/2),   -N_l^K x_K  (boundary),
