@@ -63,7 +63,10 @@ def _assemble(parts, k, nx):
     return Q, p, lam
 
 
-@pytest.mark.parametrize("nranks,k,nx", [(2, 1, 8), (2, 2, 8), (4, 1, 8), (3, 2, 6), (2, 1, 6), (2, 3, 4), (2, 2, 96), (2, 3, 40), (4, 4, 24), (2, 1, 128), (4, 2, 256)])
+# (3, 2, 30), (2, 1, 20), (3, 3, 27): strips of 10 / 10 / 9 rows -- the tiled trace preconditioner with tile rows that do not divide the
+# strip, three ranks (a middle rank with two neighbours), the replicated coarse-grid path
+@pytest.mark.parametrize("nranks,k,nx", [(2, 1, 8), (2, 2, 8), (4, 1, 8), (3, 2, 6), (2, 1, 6), (2, 3, 4), (2, 2, 96), (2, 3, 40), (4, 4, 24), (2, 1, 128), (4, 2, 256),
+                                         (3, 2, 30), (2, 1, 20), (3, 3, 27)])
 def test_strip_partition_matches_single_rank(hip_lib, tmp_path, nranks, k, nx):
     from incompressibleeulerhdg_amd import _lib
     from incompressibleeulerhdg_amd.mesh import UnitSquareMesh
