@@ -573,6 +573,9 @@ struct Engine {
     if (ev_in) { (void)hipEventDestroy(ev_in); ev_in = nullptr; }
     if (ev_halo) { (void)hipEventDestroy(ev_halo); ev_halo = nullptr; }
     if (cstream) { (void)hipStreamDestroy(cstream); cstream = nullptr; }
+    if (ev_x0) { (void)hipEventDestroy(ev_x0); ev_x0 = nullptr; }
+    if (ev_x1) { (void)hipEventDestroy(ev_x1); ev_x1 = nullptr; }
+    if (xstream) { (void)hipStreamDestroy(xstream); xstream = nullptr; }
     if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; }
     delete tab;
     tab = nullptr;
@@ -2699,20 +2702,24 @@ struct Engine {
     if (fuse_legs && nsw >= 1 && nsw <= HDG_P1_MAXSW && (n & 1) == 0) {
       // one kernel per leg (LDS tiles with recomputed halos), bit-identical to the launches below
       const int nt = (n + 1 + HDG_P1_TS - 1) / HDG_P1_TS;
-      const dim3 gt(nt, nt);
       auto down = [&](auto tag) {
         constexpr int NSW = decltype(tag)::value;
         tally(LC_MG, 8.0 * nv * 2.25);  // reads b, writes the pre-smoothed x and the coarse right-hand side
-        k_p1_down<NSW><<<gt, HDG_P1_THREADS, 0, stream>>>(n, mg_b[lev], mg_r[lev], mg_b[lev + 1]);
+        int extra = 0;
+        const SideXP sj = xp_side_slice(lev, nt, extra);
+        k_p1_down<NSW><<<dim3(nt, nt + extra), HDG_P1_THREADS, 0, stream>>>(n, mg_b[lev], mg_r[lev], mg_b[lev + 1], 0, extra, xp_period(nt, extra), sj);
       };
       auto up = [&](auto tag) {
         constexpr int NSW = decltype(tag)::value;
         tally(LC_MG, 8.0 * nv * 3.25);  // reads the coarse x, b, the pre-smoothed x, writes x
-        k_p1_up<NSW><<<gt, HDG_P1_THREADS, 0, stream>>>(n, mg_x[lev + 1], mg_b[lev], mg_r[lev], mg_x[lev]);
+        int extra = 0;
+        const SideXP sj = xp_side_slice(lev, nt, extra);
+        k_p1_up<NSW><<<dim3(nt, nt + extra), HDG_P1_THREADS, 0, stream>>>(n, mg_x[lev + 1], mg_b[lev], mg_r[lev], mg_x[lev], 0, extra, xp_period(nt, extra), sj);
       };
       if (nsw == 1) down(std::integral_constant<int, 1>{});
       else if (nsw == 2) down(std::integral_constant<int, 2>{});
       else down(std::integral_constant<int, 3>{});
+      if (lev == 0 && xp_at == 2 && !xp_riding) xp_launch(true);
       vcycle(lev + 1);
       if (nsw == 1) up(std::integral_constant<int, 1>{});
       else if (nsw == 2) up(std::integral_constant<int, 2>{});
@@ -2862,6 +2869,86 @@ struct Engine {
   // dots_out set as well, d_res then holds (z,n), (z,r), (z,z), (z,w), (n,r) (the multi-dot of that CG: *dots_out = true)
   double* tile_part = nullptr;
   long tile_part_cap = 0;
+  // trace_cg_sr on one rank: the post kernel's partial inner products are summed by k_cg_sr_reduce_scalars (one launch
+  // instead of k_reduce_parts + k_cg_sr_scalars)
+  bool defer_tile_reduce = false;
+  int tile_nblk_deferred = 0;
+  // trace_cg_sr with the tile preconditioner: the half of the update nothing reads before the next update (p, x) runs on
+  // a second stream underneath the vertex-grid V-cycle, whose launches are latency-bound and leave HBM idle
+  hipStream_t xstream = nullptr;
+  hipEvent_t ev_x0 = nullptr, ev_x1 = nullptr;
+  bool xp_pending = false, xp_inflight = false;
+  int xp_at = std::getenv("HDG_CG_XP_AT") ? std::atoi(std::getenv("HDG_CG_XP_AT")) : 1;  // experiment: where the second stream starts
+  // below this vector size the two cross-stream dependencies cost more than the overlap gains (C2: +14 us per iteration)
+  long split_min_bytes = std::getenv("HDG_CG_SPLIT_MIN_MB") ? std::atol(std::getenv("HDG_CG_SPLIT_MIN_MB")) << 20 : 0L;
+  double* xp_x = nullptr;
+  // xp_mode 1 (default): the update rides on the leg launches of the V-cycle (k_p1_down / k_p1_up side jobs, hdg_kernels.hpp:
+  // SideXP), a share of the pairs per leg by weight (the finest level's legs run 18 us, the others 6-8); what the legs did
+  // not take (no fused legs, odd tail entry) is done by xp_launch() behind the cycle.  xp_mode 0: second stream.
+  int xp_mode = std::getenv("HDG_CG_XP_MODE") ? std::atoi(std::getenv("HDG_CG_XP_MODE")) : 1;
+  double xp_w0 = std::getenv("HDG_CG_XP_W0") ? std::atof(std::getenv("HDG_CG_XP_W0")) : 1.6;
+  long xp_done = 0;      // pairs already handed to side jobs
+  double xp_wsum = 0.0;  // sum of the leg weights of one cycle
+  bool xp_riding = false;
+  void xp_ride_begin() {
+    xp_done = 0; xp_riding = false;
+    if (!xp_pending || xp_mode != 1 || periodic || general || mg_n.empty()) return;
+    static const bool fuse_legs = !std::getenv("HDG_MG_NO_FUSE");
+    if (!fuse_legs || mg_distributed()) return;
+    xp_wsum = 0.0;
+    for (size_t l = 0; l + 1 < mg_n.size() && mg_n[l] > 32 && (mg_n[l] & 1) == 0; l++) xp_wsum += 2.0 * (l == 0 ? xp_w0 : 1.0);
+    xp_riding = xp_wsum > 0.0;
+  }
+  SideXP xp_side_slice(int lev, int nt, int& extra_rows) {
+    extra_rows = 0;
+    SideXP sj{};
+    if (!xp_riding) return sj;
+    const long total = NLv >> 1;
+    long cnt = (long)std::ceil((double)total * (lev == 0 ? xp_w0 : 1.0) / xp_wsum);
+    cnt = std::min(cnt, total - xp_done);
+    if (cnt <= 0) return sj;
+    sj = SideXP{d_cgs, cg_z, tr_one, cg_p, xp_x, xp_done, xp_done + cnt};
+    xp_done += cnt;
+    const long blocks = (cnt + HDG_P1_THREADS - 1) / HDG_P1_THREADS;
+    extra_rows = (int)((blocks + nt - 1) / nt);
+    return sj;
+  }
+  // interleaving of side rows and tile rows of a leg launch (HDG_P1_SIDE_JOB)
+  static int xp_period(int nt, int extra) {
+    if (extra <= 0) return 2;
+    return extra <= nt ? std::max(2, (nt + extra) / extra) : -std::max(2, (nt + extra) / nt);
+  }
+  void xp_launch(bool overlap) {
+    if (!xp_pending) return;
+    xp_pending = false;
+    const long done = xp_riding ? xp_done : 0;
+    xp_riding = false; xp_done = 0;
+    const int nvb = vec_blocks(NLv - 2 * done);
+    if (!overlap || done > 0) {
+      if (done < (NLv >> 1) || (NLv & 1)) k_cg_sr_update_xp<<<nvb, 256, 0, stream>>>(NLv, d_cgs, cg_z, tr_one, cg_p, xp_x, done);
+      return;
+    }
+    if (!xstream) {
+      // lowest priority: the workgroups of the V-cycle legs are dispatched ahead of the (short-lived) blocks of the update
+      int pr_least = 0, pr_greatest = 0;
+      HIPCHECK(hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest));
+      static const bool no_prio = std::getenv("HDG_CG_XP_NO_PRIORITY") != nullptr;
+      if (no_prio) HIPCHECK(hipStreamCreateWithFlags(&xstream, hipStreamNonBlocking));
+      else HIPCHECK(hipStreamCreateWithPriority(&xstream, hipStreamNonBlocking, pr_least));
+      HIPCHECK(hipEventCreateWithFlags(&ev_x0, hipEventDisableTiming));
+      HIPCHECK(hipEventCreateWithFlags(&ev_x1, hipEventDisableTiming));
+    }
+    HIPCHECK(hipEventRecord(ev_x0, stream));
+    HIPCHECK(hipStreamWaitEvent(xstream, ev_x0, 0));
+    k_cg_sr_update_xp<<<nvb, 256, 0, xstream>>>(NLv, d_cgs, cg_z, tr_one, cg_p, xp_x);
+    HIPCHECK(hipEventRecord(ev_x1, xstream));
+    xp_inflight = true;
+  }
+  void xp_join() {
+    if (!xp_inflight) return;
+    xp_inflight = false;
+    HIPCHECK(hipStreamWaitEvent(stream, ev_x1, 0));
+  }
   bool trace_precond(const double* r, double* z, double* w_out = nullptr, bool* dots_out = nullptr) {
     if (dots_out) *dots_out = false;
     if (cfg.trace_precond == 0) {
@@ -2891,7 +2978,11 @@ struct Engine {
         const int grid_pre = 8 * ((ntx * nty_pre + 7) / 8), grid = 8 * ((ntx * nty + 7) / 8);  // XCD-aware tile order (HDG_TILE_OF_BLOCK)
         tally(LC_TRACE_SMOOTH, 3 * bL());
         k_trace_pre_tile<KK><<<grid_pre, TT::NTHREADS, 0, stream>>>(ntx, nty_pre, g, pre, pdt(), r, c0, c1, c2, ch_d, wL2);
+        xp_ride_begin();  // the deferred half of the CG update: on the legs of the vertex-grid cycle ...
+        if (!xp_riding && xp_at == 1) xp_launch(true);  // ... or underneath it on its own stream
         coarse_correction(wL2);
+        xp_launch(true);  // (not started by now: a cycle without the hook)
+        xp_join();        // the post kernel overwrites z
         tally(LC_TRACE_SMOOTH, (w_out ? 4 : 3) * bL() + nvtx);
         const long nblk = (long)ntx * nty;
         double* part = nullptr;
@@ -2908,7 +2999,8 @@ struct Engine {
                                                                           std::sqrt(dt.elen[1]), c0, c1, c2, z, w_out, nullptr);
         if (part) {
           tally(LC_OTHER, 0.0);
-          reduce_parts_allreduce((int)nblk, 5, part);  // second reduction stage (+ the all-reduce across ranks) -> d_res
+          if (defer_tile_reduce) tile_nblk_deferred = (int)nblk;  // one rank: summed by the kernel that forms the CG scalars
+          else reduce_parts_allreduce((int)nblk, 5, part);        // second reduction stage (+ the all-reduce across ranks) -> d_res
           *dots_out = true;
         }
       };
@@ -3111,6 +3203,23 @@ struct Engine {
   // already taken the step to x_{k+1}, which is harmless (a further CG step) and keeps the host off the critical path.
   // Returns the number of iterations the convergence test needed (the extra step is not counted).
   int trace_cg_sr(double* b, double* x, double rtol, int maxit, bool strict) {
+    const bool no_split = cg_no_split, no_fused = cg_no_fused_scalars;
+    auto leave = [&]() {  // a deferred p / x update left over at the exit is the step beyond the tested iterate: dropped
+      xp_pending = false;
+      defer_tile_reduce = false; tile_nblk_deferred = 0;
+      if (xp_inflight) { xp_inflight = false; (void)hipStreamWaitEvent(stream, ev_x1, 0); }
+    };
+    try {
+      defer_tile_reduce = comm->size == 1 && !no_fused;
+      const int its = trace_cg_sr_body(b, x, rtol, maxit, strict, !no_split && comm->size == 1 && use_trace_tile() && NLv * 8L >= split_min_bytes);
+      leave();
+      return its;
+    } catch (...) {
+      leave();
+      throw;
+    }
+  }
+  int trace_cg_sr_body(double* b, double* x, double rtol, int maxit, bool strict, bool split) {
     project_const(b);
     FlowScope flow_(*this);
     if (fl.Dx > 1) { halo_L(b, fl.Dx - 1); fl.set(b, fl.Dx - 1); }
@@ -3144,6 +3253,7 @@ struct Engine {
     bool restart = true, true_residual = true;  // the first pass starts from r = b - T x as well
     static const double floor_c = std::getenv("HDG_CG_FLOOR_C") ? std::atof(std::getenv("HDG_CG_FLOOR_C")) : 32.0;
     auto replace_residual = [&](const char* why, double at, bool is_breakdown) {
+      xp_launch(false);  // the true residual needs the current iterate
       if (drifts >= 2) throw NotConverged{std::string("trace CG: ") + why + " after two residual replacements that confirmed a drifted recurrence"};
       replaced++;
       trigger_nrm = at; trigger_breakdown = is_breakdown;
@@ -3160,10 +3270,21 @@ struct Engine {
       if (!have_dots) multidot(NLv, cg_z, {tr_one, cg_r, cg_z, cg_Ap}, nullptr, KL, true);  // (z,n), (z,r), (z,z), (z,w), (n,r) -> d_res
       tally(LC_OTHER, 0.0);
       tally(LC_VEC, bL() * 11);  // k_cg_sr_update: reads z, n, w, p, s, x, r; writes p, s, x, r
-      k_cg_sr_scalars<<<1, 1, 0, stream>>>(d_res, d_cgs, tr_one_nn, restart ? 1 : 0, direct_host() ? h_cgs : nullptr);  // + snapshot in pinned memory
+      if (have_dots && tile_nblk_deferred > 0) {
+        k_cg_sr_reduce_scalars<<<1, 1024, 0, stream>>>(tile_nblk_deferred, tile_part, d_res, d_cgs, tr_one_nn, restart ? 1 : 0, direct_host() ? h_cgs : nullptr);
+        tile_nblk_deferred = 0;
+        n_reduce++;
+      } else
+        k_cg_sr_scalars<<<1, 1, 0, stream>>>(d_res, d_cgs, tr_one_nn, restart ? 1 : 0, direct_host() ? h_cgs : nullptr);  // + snapshot in pinned memory
       if (!direct_host()) HIPCHECK(hipMemcpyAsync(h_cgs, d_cgs, sizeof(double) * 8, hipMemcpyDeviceToHost, stream));
       HIPCHECK(hipEventRecord(cg_ev, stream));
-      k_cg_sr_update<<<nvb, 256, 0, stream>>>(NLv, d_cgs, cg_z, tr_one, cg_Ap, cg_p, cg_s, x, cg_r);
+      if (split) {
+        // r first (the next preconditioner application waits for it); p and x when that application reaches its V-cycle
+        k_cg_sr_update_r<<<nvb, 256, 0, stream>>>(NLv, d_cgs, cg_Ap, cg_s, cg_r);
+        xp_pending = true; xp_x = x;
+        if (xp_at == 0 && xp_mode != 1) xp_launch(true);
+      } else
+        k_cg_sr_update<<<nvb, 256, 0, stream>>>(NLv, d_cgs, cg_z, tr_one, cg_Ap, cg_p, cg_s, x, cg_r);
       fl.set(cg_s, restart ? fl.get(cg_Ap) : std::min(fl.get(cg_s), fl.get(cg_Ap)));
       fl.set(cg_r, std::min(fl.get(cg_r), fl.get(cg_s)));
       fl.set(x, 0);
@@ -3174,6 +3295,7 @@ struct Engine {
       const bool breakdown = h_cgs[6] == 1.0;  // alpha was set to 0: the update just queued leaves x alone
       double zz = h_cgs[4];
       if (h_cgs[6] == 2.0) {  // z almost parallel to the null vector: measure the projected norm explicitly
+        xp_launch(false);  // (the deferred update reads the unprojected z)
         axpby(NLv, -h_cgs[3], tr_one, 1.0, cg_z);
         fl.set(cg_z, 0);
         zz = dot(NLv, cg_z, cg_z, KL);
@@ -3187,6 +3309,7 @@ struct Engine {
       if (cg_floor > 0.0 && nrm <= cg_floor) return its;  // backward-error stop (experiment, see pressure_solve)
       if (was_true && replaced > 0) {
         // the true preconditioned residual after a replacement: at its rounding floor?
+        xp_launch(false);
         const double xn = std::sqrt(std::max(dot(NLv, x, x, KL), 0.0));
         if (debug_cg()) fprintf(stderr, "[cg] it %d: true |z| %.3e, floor %.3e (|x| %.3e)\n", its, nrm, floor_c * 2.220446049250313e-16 * xn, xn);
         if (nrm <= floor_c * 2.220446049250313e-16 * xn) { ev_cg_floor_exits++; return its; }
@@ -3210,6 +3333,7 @@ struct Engine {
   }
   // residual replacements / floor exits of the condensed solves since the last reset (hdg_get_solver_events)
   long ev_cg_replacements = 0, ev_cg_floor_exits = 0;
+  bool cg_no_split = std::getenv("HDG_CG_NO_SPLIT_UPDATE") != nullptr, cg_no_fused_scalars = std::getenv("HDG_CG_NO_FUSED_SCALARS") != nullptr;  // read per engine
   int cg_force_replace = std::getenv("HDG_CG_FORCE_REPLACE") ? std::atoi(std::getenv("HDG_CG_FORCE_REPLACE")) : 0;  // test hook, read per engine
   int trace_cg(double* b, double* x, double rtol = -1.0, int maxit = -1, bool strict = true) {
     if (rtol < 0) rtol = cfg.trace_rtol;

@@ -2332,6 +2332,43 @@ __global__ void k_cg_sr_update(long N, const double* __restrict__ sc, const doub
     r[it_] = fma(-alpha, sv, r[it_]);
   }
 }
+// The same update in two launches (one rank, tile preconditioner): the half the next preconditioner application waits
+// for -- s = w + beta s ; r -= alpha s -- and the half nothing reads before the next update -- p = (z - c n) + beta p ;
+// x += alpha p --, which Engine::trace_cg_sr queues on a second stream underneath the latency-bound vertex-grid V-cycle.
+__global__ void k_cg_sr_update_r(long N, const double* __restrict__ sc, const double* __restrict__ w, double* __restrict__ s,
+                                 double* __restrict__ r) {
+  const double alpha = sc[1], beta = sc[2];
+  HDG_VEC_PROLOGUE
+  for (long i = tid_; i < NP2_; i += stride_) {
+    const hdg_d2 wv = as2(w)[i], rv = as2(r)[i];
+    const hdg_d2 sv = (beta == 0.0) ? wv : fma2(beta, as2(s)[i], wv);
+    as2(s)[i] = sv;
+    as2(r)[i] = fma2(-alpha, sv, rv);
+  }
+  if (tail_) {
+    const double sv = (beta == 0.0) ? w[it_] : fma(beta, s[it_], w[it_]);
+    s[it_] = sv;
+    r[it_] = fma(-alpha, sv, r[it_]);
+  }
+}
+__global__ void k_cg_sr_update_xp(long N, const double* __restrict__ sc, const double* __restrict__ z, const double* __restrict__ nvec,
+                                  double* __restrict__ p, double* __restrict__ x, long ibeg = 0) {
+  const double alpha = sc[1], beta = sc[2], c = sc[3];
+  HDG_VEC_PROLOGUE
+  for (long i = ibeg + tid_; i < NP2_; i += stride_) {  // pairs before ibeg: done by the side jobs of the V-cycle legs
+    const hdg_d2 zp = fma2(-c, as2(nvec)[i], as2(z)[i]);
+    const hdg_d2 xv = as2(x)[i];
+    const hdg_d2 pv = (beta == 0.0) ? zp : fma2(beta, as2(p)[i], zp);
+    as2(p)[i] = pv;
+    as2(x)[i] = fma2(alpha, pv, xv);
+  }
+  if (tail_) {
+    const double zp = fma(-c, nvec[it_], z[it_]);
+    const double pv = (beta == 0.0) ? zp : fma(beta, p[it_], zp);
+    p[it_] = pv;
+    x[it_] = fma(alpha, pv, x[it_]);
+  }
+}
 // y = a*x + b*y
 template <bool NT>
 __global__ void k_axpby(long N, double a, const double* __restrict__ x, double b, double* __restrict__ y) {
@@ -2467,6 +2504,54 @@ __global__ void k_reduce_parts(int nblocks, int nv, const double* __restrict__ p
     for (int w = 0; w < (int)(blockDim.x >> 6); w++) tot += sm[w];
     res[k] = tot;
     if (hres) hres[k] = tot;
+  }
+}
+// Second reduction stage of the tile preconditioner's five inner products AND the scalars of the single-reduction CG in
+// one launch (one rank: no all-reduce in between): one workgroup of 1024 threads, fixed summation order (deterministic).
+__global__ __launch_bounds__(1024) void k_cg_sr_reduce_scalars(int nblocks, const double* __restrict__ part, double* __restrict__ res,
+                                                               double* __restrict__ sc, double nn, int first, double* __restrict__ hsc) {
+  double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int b = threadIdx.x; b < nblocks; b += 1024) {
+#pragma unroll
+    for (int q = 0; q < 5; q++) acc[q] += part[(long)b * 5 + q];
+  }
+  __shared__ double sm[16][5];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int q = 0; q < 5; q++) {
+    const double sv = wave_sum(acc[q]);
+    if (lane == 0) sm[wv][q] = sv;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  double r5[5];
+#pragma unroll
+  for (int q = 0; q < 5; q++) {
+    double t = 0.0;
+    for (int w = 0; w < 16; w++) t += sm[w][q];
+    r5[q] = t;
+    res[q] = t;
+  }
+  // == k_cg_sr_scalars
+  const double c = r5[0] / nn;
+  const double rzn = r5[1] - c * r5[4];
+  const double zz = r5[2] - c * r5[0];
+  if (!(zz > 1e-6 * r5[2])) sc[6] = 2.0;
+  const double beta = first ? 0.0 : rzn / sc[0];
+  const double pAp = first ? r5[3] : r5[3] - beta * rzn / sc[1];
+  double alpha = rzn / pAp;
+  if (rzn == 0.0) alpha = 0.0;
+  else if (!(pAp > 0.0)) { sc[6] = 1.0; alpha = 0.0; }
+  sc[3] = c;
+  sc[4] = zz;
+  sc[7] = r5[2];
+  sc[5] = pAp;
+  sc[2] = (rzn == 0.0) ? 0.0 : beta;
+  sc[1] = alpha;
+  sc[0] = rzn;
+  if (hsc) {
+#pragma unroll
+    for (int q = 0; q < 8; q++) hsc[q] = sc[q];
   }
 }
 // coefficient list passed by value (Gram-Schmidt / basis updates)
@@ -2774,6 +2859,47 @@ __global__ void k_fill(long N, double* __restrict__ x, double v) {
 #define HDG_P1_TS 32
 #define HDG_P1_MAXSW 3
 #define HDG_P1_THREADS 1024
+// Side job of a leg launch (Engine::trace_cg_sr, one rank): the legs are latency-bound (8 barrier-separated LDS phases on a
+// grid of at most 33 x 33 tiles) and leave HBM idle, so the half of the CG update that nothing reads before the next
+// update -- p = (z - c n) + beta p ; x += alpha p (k_cg_sr_update_xp) -- rides along: the workgroups of the tile rows
+// >= nrows of a leg launch each take 1024 sixteen-byte pairs of the slice [i0, i1) instead of a tile.  (A second stream for
+// the same purpose gained 14 us per CG iteration of the 64 possible: two cross-stream dependencies cost 17 us.)
+struct SideXP {
+  const double* sc;
+  const double* z;
+  const double* nvec;
+  double* p;
+  double* x;
+  long i0, i1;
+};
+__device__ __forceinline__ void side_xp(const SideXP& sj, long blk, long nblk) {
+  const double alpha = sj.sc[1], beta = sj.sc[2], c = sj.sc[3];
+  for (long i = sj.i0 + blk * HDG_P1_THREADS + threadIdx.x; i < sj.i1; i += nblk * HDG_P1_THREADS) {
+    const hdg_d2 zp = fma2(-c, as2(sj.nvec)[i], as2(sj.z)[i]);
+    const hdg_d2 xv = as2(sj.x)[i];
+    const hdg_d2 pv = (beta == 0.0) ? zp : fma2(beta, as2(sj.p)[i], zp);
+    as2(sj.p)[i] = pv;
+    as2(sj.x)[i] = fma2(alpha, pv, xv);
+  }
+}
+// Rows of a leg launch with `extra` side rows: the less numerous kind of row (side rows for period > 0, tile rows for
+// period < 0) takes the last row of every group of |period| rows until it is used up, so that the short-lived side workgroups
+// are dispatched in between the tiles instead of behind them (the finest level has twice as many tiles as the chip has
+// slots for).  by = the tile row of a workgroup that has one.
+#define HDG_P1_SIDE_JOB                                                                                              \
+  int by = (int)blockIdx.y;                                                                                          \
+  if (extra > 0) {                                                                                                   \
+    const int per_ = period < 0 ? -period : period;                                                                  \
+    const int nminor_ = period < 0 ? (int)gridDim.y - extra : extra;                                                 \
+    const int q_ = by / per_, rem_ = by - q_ * per_;                                                                 \
+    const bool minor_ = rem_ == per_ - 1 && q_ < nminor_;                                                            \
+    const int idx_ = minor_ ? q_ : by - (q_ < nminor_ ? q_ : nminor_);                                               \
+    if ((period < 0) != minor_) {                                                                                    \
+      side_xp(sj, (long)idx_ * gridDim.x + blockIdx.x, (long)extra * gridDim.x);                                     \
+      return;                                                                                                        \
+    }                                                                                                                \
+    by = idx_;                                                                                                       \
+  }
 // region-local stencil: (gi, gj) global vertex, (li, lj) local; false if a neighbour inside the domain lies
 // outside the loaded region (the point is then part of the garbage ring and is skipped).
 // The diagonal is 4 (interior), 2 (boundary edge) or 1 (corner): its reciprocal is exact, so multiplying by
@@ -2813,12 +2939,13 @@ __device__ __forceinline__ void p1_tile_sweeps(double* X, const double* B, int n
 // down leg: x = 0, nsw sweeps on A x = b, r = b - A x, bc = R r (coarse right-hand side); x is stored to xpre
 template <int NSW>
 __global__ __launch_bounds__(HDG_P1_THREADS) void k_p1_down(int n, const double* __restrict__ b, double* __restrict__ xpre,
-                                                            double* __restrict__ bc, int jt0 = 0) {
+                                                            double* __restrict__ bc, int jt0 = 0, int extra = 0, int period = 2, SideXP sj = SideXP{}) {
   constexpr int H = 2 * NSW + 2, W = HDG_P1_TS + 2 * H;
   __shared__ double X[W * W];
   __shared__ double B[W * W];
+  HDG_P1_SIDE_JOB
   const int st = n + 1;
-  const int i0 = blockIdx.x * HDG_P1_TS, j0 = (blockIdx.y + jt0) * HDG_P1_TS, gi0 = i0 - H, gj0 = j0 - H;  // jt0: first tile row of this launch
+  const int i0 = blockIdx.x * HDG_P1_TS, j0 = (by + jt0) * HDG_P1_TS, gi0 = i0 - H, gj0 = j0 - H;  // jt0: first tile row of this launch
   for (int p = threadIdx.x; p < W * W; p += HDG_P1_THREADS) {
     const int lj = p / W, li = p - lj * W, gi = gi0 + li, gj = gj0 + lj;
     const bool in = gi >= 0 && gj >= 0 && gi <= n && gj <= n;
@@ -2862,12 +2989,14 @@ __global__ __launch_bounds__(HDG_P1_THREADS) void k_p1_down(int n, const double*
 // DIFFERENT buffers: a workgroup reads the halo of its tile while its neighbours store theirs.
 template <int NSW>
 __global__ __launch_bounds__(HDG_P1_THREADS) void k_p1_up(int n, const double* __restrict__ xc, const double* __restrict__ b,
-                                                          const double* __restrict__ xpre, double* __restrict__ x, int jt0 = 0) {
+                                                          const double* __restrict__ xpre, double* __restrict__ x, int jt0 = 0, int extra = 0, int period = 2,
+                                                          SideXP sj = SideXP{}) {
   constexpr int H = 2 * NSW, W = HDG_P1_TS + 2 * H;
   __shared__ double X[W * W];
   __shared__ double B[W * W];
+  HDG_P1_SIDE_JOB
   const int st = n + 1, nc = n >> 1, sc = nc + 1;
-  const int i0 = blockIdx.x * HDG_P1_TS, j0 = (blockIdx.y + jt0) * HDG_P1_TS, gi0 = i0 - H, gj0 = j0 - H;  // jt0: first tile row of this launch
+  const int i0 = blockIdx.x * HDG_P1_TS, j0 = (by + jt0) * HDG_P1_TS, gi0 = i0 - H, gj0 = j0 - H;  // jt0: first tile row of this launch
   for (int p = threadIdx.x; p < W * W; p += HDG_P1_THREADS) {
     const int lj = p / W, li = p - lj * W, i = gi0 + li, j = gj0 + lj;
     if (i < 0 || j < 0 || i > n || j > n) { X[p] = 0.0; B[p] = 0.0; continue; }
