@@ -270,8 +270,18 @@ __global__ __launch_bounds__(TraceTile<K>::NTHREADS) __attribute__((amdgpu_waves
 #pragma unroll
     for (int q = 0; q < NT; q++) Zs[(plane_of<NL>(q) * H3 + lj) * W3 + li] = z[q];
   }
-  __syncthreads();
+  // r of this thread's stage-1 corners: requested BEFORE the barrier, so that the loads travel together with those of stage 0
+  // (the compiler does not move a load across s_barrier; behind it the round trip was exposed once more per workgroup)
   double r0[KMAX][NT], z1[KMAX][NT], d0[KMAX][NT];
+#pragma unroll
+  for (int k = 0; k < KMAX; k++) {
+    const int idx = threadIdx.x + k * TT::NTHREADS;
+    const int lj = idx / W2, li = idx - lj * W2;
+    CornerInfo c = corner_info(g, tr, i0 - 2 + li, j0 - 2 + lj);
+    if (idx >= TT::N2) c.in_x = c.in_y = false;
+    load_corner<NL>(r, g, c, r0[k]);
+  }
+  __syncthreads();
   double dots[5] = {0.0, 0.0, 0.0, 0.0, 0.0};  // (z,n), (z,r), (z,z), (z,w), (n,r) of this thread's tile corners
   // stage 1 on the halo-2 region: r0 = r - T z0, d0 = c0 Dinv r0, z1 = z0 + d0
 #pragma unroll
@@ -282,16 +292,15 @@ __global__ __launch_bounds__(TraceTile<K>::NTHREADS) __attribute__((amdgpu_waves
       const int jc = j0 - 2 + lj;
       const CornerInfo c = corner_info(g, tr, i0 - 2 + li, jc);
 #pragma unroll
-      for (int q = 0; q < NT; q++) r0[k][q] = z1[k][q] = d0[k][q] = 0.0;
+      for (int q = 0; q < NT; q++) z1[k][q] = d0[k][q] = 0.0;  // (r0 holds r: zeros where the corner or an edge does not exist)
       if (c.exists) {
-        double own[NT], y[3][NL], rr[NT];
+        double own[NT], y[3][NL];
         lds_trace_stencil<K, W3, H3>(Zs, li + 1, lj + 1, c.in_x, c.in_y, c.below, c.left, T, own, y[0], y[1], y[2]);
-        load_corner<NL>(r, g, c, rr);
 #pragma unroll
         for (int m = 0; m < NL; m++) {
-          r0[k][m] = rr[m] - y[0][m];
-          r0[k][NL + m] = rr[NL + m] - y[2][m];
-          r0[k][2 * NL + m] = rr[2 * NL + m] - y[1][m];
+          r0[k][m] -= y[0][m];
+          r0[k][NL + m] -= y[2][m];
+          r0[k][2 * NL + m] -= y[1][m];
         }
         corner_dinv<NL>(T, c, c0, r0[k], d0[k]);
 #pragma unroll
@@ -334,6 +343,19 @@ __global__ __launch_bounds__(TraceTile<K>::NTHREADS) __attribute__((amdgpu_waves
     }
   }
   if (!w_out) return;  // uniform
+  // r of the tile corners for the inner products: requested before the barrier as well (r0, z1, d0 are dead)
+  double rr3[KMAX][NT];
+  if (DOTS) {
+#pragma unroll
+    for (int k = 0; k < KMAX; k++) {
+      const int idx = threadIdx.x + k * TT::NTHREADS;
+      const int lj = idx / W2, li = idx - lj * W2;
+      const int jc = j0 - 2 + lj;
+      CornerInfo c = corner_info(g, tr, i0 - 2 + li, jc);
+      if (!(idx < TT::N2 && li >= 2 && li < W2 - 2 && lj >= 2 && lj < H2 - 2 && c.exists && jc < tr.jhi)) c.in_x = c.in_y = false;
+      load_corner<NL>(r, g, c, rr3[k]);
+    }
+  }
   __syncthreads();
   // stage 3 on the tile: w = T z2
 #pragma unroll
@@ -355,8 +377,7 @@ __global__ __launch_bounds__(TraceTile<K>::NTHREADS) __attribute__((amdgpu_waves
             // separate multi-dot pass over z, n, r, w is not needed.  The null vector n (the constant) has the entry
             // sqrt(edge length) in mode 0 of every edge that exists and zeros elsewhere -- what edge_prolong gives for
             // vertex values 1; entries of edges that do not exist are zero in z and r.
-            double rr[NT];
-            load_corner<NL>(r, g, c, rr);
+            const double* rr = rr3[k];
             dots[0] += sH * own[0] + sD * own[NL] + sV * own[2 * NL];  // own = z2 of this corner (from LDS)
             dots[4] += sH * rr[0] + sD * rr[NL] + sV * rr[2 * NL];
 #pragma unroll

@@ -35,5 +35,6 @@ def test_split_cg_update_equals_the_one_launch_update(hip_lib, k, nx, monkeypatc
         res[tag] = (Q.dat.data.copy(), p.dat.data.copy(), sums / np.maximum(cnt, 1))
     for tag in ("ride", "stream"):
         assert _rel(res[tag][0], res["one"][0]) < 1e-9 and _rel(res[tag][1], res["one"][1]) < 1e-9, tag
-        # condensed CG: the same counts; tentative velocity (rtol 1e-10 on a right-hand side that differs at 1e-12): within one
-        assert np.array_equal(res[tag][2][1:], res["one"][2][1:]) and abs(res[tag][2][0] - res["one"][2][0]) <= 1.0, (tag, res[tag][2], res["one"][2])
+        # the warm starts of later solves differ at 1e-12 (the dropped step): a count at the edge of its tolerance may move by one
+        # (tentative velocity: the s-step cycle lengths follow the observed rates, so a solve may take a cycle more or less)
+        assert np.all(np.abs(res[tag][2][1:] - res["one"][2][1:]) <= 1.0) and abs(res[tag][2][0] - res["one"][2][0]) <= 3.0, (tag, res[tag][2], res["one"][2])

@@ -35,7 +35,10 @@ def test_sstep_tail_against_the_gmres_tail_and_the_oracle(hip_lib, tmp_path, k, 
     res = {}
     for tag, env in (("sstep", {}), ("gmres", {"HDG_TAIL_GMRES": "1"}), ("aug", {"HDG_SSTEP_AUG": "1"}), ("aug2", {"HDG_SSTEP_AUG": "2", "HDG_SSTEP_MAX": "5"})):
         res[tag], log = _worker(tmp_path, tag, k, nx, 2, env)
-        assert ("[sstep] cycle" in log) == (tag != "gmres"), tag
+        # (the GMRES-tail run may still show s-step cycles: a WHOLE solve that the Chebyshev iteration does not take -- its
+        # ellipse predicts > 64 iterations -- runs as s-step cycles in either mode; the first solve of a run from smooth data,
+        # whose opening Arnoldi cycle spans a nearly invariant subspace, can fall on either side of that line)
+        assert "[sstep] cycle" in log if tag != "gmres" else "[gmres]" in log, tag
     for tag in ("gmres", "aug", "aug2"):
         for name in ("Q", "p", "lam"):
             assert _rel(res[tag][name], res["sstep"][name]) < 1e-9, (tag, name)
