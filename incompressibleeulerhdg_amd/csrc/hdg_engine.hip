@@ -2426,7 +2426,13 @@ struct Engine {
       const double f_hi = (e_hi > 0 ? e_hi : (hyb ? (cfg.degree == 1 ? 1.5 : 1.3) : 1.15)) * ch_widen[didx];
       lo *= f_lo; hi *= f_hi;
       if (ch_lmin[didx] > 0) { lo = std::min(lo, ch_lmin[didx]); hi = std::max(hi, ch_lmax[didx]); }
-      ch_lmin[didx] = lo; ch_lmax[didx] = hi;
+      // An opening cycle that all but solves the system (the first solve of a run from smooth data: 2e-8 in six iterations
+      // where 1e-4 is normal) spans a nearly invariant subspace: its extreme Ritz values move by factors under a perturbation
+      // of 1e-12 of the data (seen at k = 2, 128^2: smallest Ritz value 0.70 or 0.21, the latter sends 64 solves to the slow
+      // whole-solve path).  Such bounds serve this solve only; the next solve of the stage estimates afresh.
+      static const double prov = std::getenv("HDG_CHEB_PROVISIONAL") ? std::atof(std::getenv("HDG_CHEB_PROVISIONAL")) : 1e-6;
+      if (beta <= prov * beta0) { ch_lmin[didx] = ch_lmax[didx] = -1.0; }
+      else { ch_lmin[didx] = lo; ch_lmax[didx] = hi; }
       if (debug_on()) {
         fprintf(stderr, "[cheb] stage %d ritz:", didx);
         for (auto v : ritz) fprintf(stderr, " %.3f%+.3fi", v.real(), v.imag());
@@ -2845,7 +2851,10 @@ struct Engine {
     static const bool fuse = !std::getenv("HDG_TRACE_NO_FUSE");
     static const bool strips = !std::getenv("HDG_TRACE_NO_TILE_STRIPS");  // round 4: the tile kernels on a strip partition too
     // k = 4: the post kernel needs 274 VGPRs (15 trace values per corner and stage): 5.88 instead of 5.65 ms per solve at 512^2
-    return !off && fuse && nsm == 2 && cfg.trace_precond == 1 && !periodic && !general && halo_on && K <= 3 &&
+    // periodic square: the wrapped ghost rows play the neighbours' part (every tile reaches at most 3 columns / 5 rows beyond)
+    static const bool per_ok = !std::getenv("HDG_TRACE_NO_TILE_PERIODIC");
+    if (periodic && !(per_ok && g.nx >= 16 && g.ny >= 8)) return false;
+    return !off && fuse && nsm == 2 && cfg.trace_precond == 1 && !general && halo_on && K <= 3 &&
            (comm->size == 1 || (strips && g.ny >= TILE_HALO_R));
   }
   // vertex-grid correction of the trace preconditioner: mg_b[0] <- restriction of `res` (owned edges), one V-cycle, result in
@@ -2853,6 +2862,11 @@ struct Engine {
   void coarse_correction(const double* res) {
     const int partial = mg_gather ? 1 : 0;
     tally(LC_MG, bL() + 8.0 * (g.nx + 1.0) * (g.ny + 1.0));
+    if (periodic) {  // (row -1 of `res` comes from the pre kernel's ghost rows)
+      k_trace_to_p1p<<<corner_grid(), bs(), 0, stream>>>(g, NL, res, mg_b[0], dt.elen[0], dt.elen[2], dt.elen[1]);
+      run_vcycle();
+      return;
+    }
     k_trace_to_p1<<<corner_grid_all(), bs(), 0, stream>>>(g_all, NL, res, mg_b[0], dt.elen[0], dt.elen[2], dt.elen[1], partial);
     if (mg_distributed()) { vcycle_distributed_top(); return; }
     if (mg_gather) {
@@ -2963,8 +2977,9 @@ struct Engine {
       const double nvtx = 8.0 * (g.nx + 1.0) * (g.ny + 1.0);
       // strip partition: the ONE exchange of a CG iteration -- r, 5 ghost rows deep (the pre kernel computes z on 3 ghost rows
       // towards every neighbour from r on 5; the post kernel then finds its halo of z and r locally)
-      const bool has_lo = comm->size > 1 && comm->rank > 0, has_hi = comm->size > 1 && comm->rank < comm->size - 1;
-      if (comm->size > 1) {
+      const bool has_lo = periodic || (comm->size > 1 && comm->rank > 0), has_hi = periodic || (comm->size > 1 && comm->rank < comm->size - 1);
+      if (periodic) halo_L(r, TILE_HALO_R);  // (k_wrap_rows: every ghost row from the opposite side)
+      else if (comm->size > 1) {
         if (fl.get(r) < TILE_HALO_R) { halo_L(r, TILE_HALO_R); fl.set(r, TILE_HALO_R); }
         else if (flow_check) flow_check_input(r, FL, TILE_HALO_R);
       }
@@ -2973,7 +2988,7 @@ struct Engine {
         typedef TraceTile<KK> TT;
         TileRows pre{has_lo ? -3 : 0, g.nyc + (has_hi ? 3 : 0), 0, 0}, post{0, g.nyc, -3, g.nyc + 3};
         pre.rlo = pre.jlo - 2; pre.rhi = pre.jhi + 2;
-        const int ntx = (g.nx + 1 + TT::TW - 1) / TT::TW;
+        const int ntx = (g.nx + (periodic ? 0 : 1) + TT::TW - 1) / TT::TW;
         const int nty_pre = (pre.jhi - pre.jlo + TT::TH - 1) / TT::TH, nty = (post.jhi - post.jlo + TT::TH - 1) / TT::TH;
         const int grid_pre = 8 * ((ntx * nty_pre + 7) / 8), grid = 8 * ((ntx * nty + 7) / 8);  // XCD-aware tile order (HDG_TILE_OF_BLOCK)
         tally(LC_TRACE_SMOOTH, 3 * bL());

@@ -17,7 +17,8 @@
 // thread keeps the same corners through all stages (the index map of the halo-2 region; stages that act on a smaller region
 // mask the rest).
 //
-// Non-periodic meshes.  Same arithmetic per corner as trace_stencil / k_trace_smooth.  Round 4: strips as well.  A launch
+// Same arithmetic per corner as trace_stencil / k_trace_smooth.  Round 4: strips as well, and the doubly periodic square
+// (corner_info: wrapped columns; in y a strip whose ghost rows are its own opposite rows).  A launch
 // COMPUTES the corner rows [jlo, jhi) of the rank's strip (local numbering, ghost rows included) and READS the rows
 // [rlo, rhi) = the computed rows +- the kernel's halo; a corner outside that window or outside the GLOBAL mesh is a zero
 // (it lies beyond the dependency cone of every computed row).  One rank: jlo = 0, jhi = ny + 1, the window is the mesh.
@@ -93,6 +94,7 @@ __device__ __forceinline__ void lds_trace_stencil(const double* __restrict__ A, 
   const int tile_y = tile_v / ntx, tile_x = tile_v - tile_y * ntx;
 struct CornerInfo {
   bool exists, in_x, in_y, below, left;
+  bool own_x;  // the column is one of the mesh's own (periodic in x: a wrapped halo column is NOT; stores / inner products skip it)
   int vH, vV;  // block-Jacobi variants of the corner's H and V edge
   long o;      // offset of the corner inside a trace plane
 };
@@ -103,7 +105,23 @@ struct TileRows {
 __device__ __forceinline__ CornerInfo corner_info(const Geo& g, const TileRows& tr, int i, int j) {
   CornerInfo c;
   const int gj = g.joff + j;  // global corner row
+  if (g.px) {
+    // doubly periodic square: nx corner columns, every column index wraps; in y the strip pretends to lie inside a taller mesh
+    // (Engine::construct) and its ghost rows hold the rows of the opposite side, as on a strip between two neighbours
+    c.exists = gj >= 0 && gj <= g.nyg && j >= tr.rlo && j < tr.rhi;
+    c.own_x = i >= 0 && i < g.nx;
+    const int iw = i < 0 ? i + g.nx : (i >= g.nx ? i - g.nx : i);  // tiles reach at most 3 columns beyond either end; nx >= 16 (use_trace_tile)
+    c.in_x = c.exists;
+    c.in_y = c.exists && gj < g.nyg;
+    c.below = gj > 0;
+    c.left = true;
+    c.vH = gj == 0 ? 1 : (gj == g.nyg ? 2 : 0);
+    c.vV = 0;
+    c.o = (long)(j + GH) * g.P + iw;
+    return c;
+  }
   c.exists = i >= 0 && i <= g.nx && gj >= 0 && gj <= g.nyg && j >= tr.rlo && j < tr.rhi;
+  c.own_x = true;
   c.in_x = c.exists && i < g.nx;
   c.in_y = c.exists && gj < g.nyg;
   c.below = gj > 0;
@@ -210,7 +228,7 @@ __global__ __launch_bounds__(TraceTile<K>::NTHREADS) void k_trace_pre_tile(int n
         }
 #pragma unroll
         for (int q = 0; q < NT; q++) Zs[(plane_of<NL>(q) * H1 + (lj - 1)) * W1 + (li - 1)] = z[q];
-        if (c.exists && li >= 2 && li < W2 - 2 && lj >= 2 && lj < H2 - 2 && jc < tr.jhi) store_corner<NL>(z_out, g, c, z);
+        if (c.exists && c.own_x && li >= 2 && li < W2 - 2 && lj >= 2 && lj < H2 - 2 && jc < tr.jhi) store_corner<NL>(z_out, g, c, z);
       }
     }
   }
@@ -224,7 +242,7 @@ __global__ __launch_bounds__(TraceTile<K>::NTHREADS) void k_trace_pre_tile(int n
       if (li >= 2 && li < W2 - 2 && lj >= 2 && lj < H2 - 2) {
         const int jc = j0 - 2 + lj;
         const CornerInfo c = corner_info(g, tr, i0 - 2 + li, jc);
-        if (c.exists && jc < tr.jhi) {
+        if (c.exists && c.own_x && jc < tr.jhi) {
           double own[NT], y[3][NL], res[NT];
           lds_trace_stencil<K, W1, H1>(Zs, li - 1, lj - 1, c.in_x, c.in_y, c.below, c.left, T, own, y[0], y[1], y[2]);
 #pragma unroll
@@ -259,7 +277,16 @@ __global__ __launch_bounds__(TraceTile<K>::NTHREADS) __attribute__((amdgpu_waves
     const CornerInfo c = corner_info(g, tr, i, j);
     double z[NT];
     load_corner<NL>(z_in, g, c, z);
-    if (c.exists) {
+    if (c.exists && g.px) {
+      // periodic vertex grid: nx x ny vertices, both indices wrap (j, i within 3 of the strip)
+      const int n = g.nx, m = g.ny;
+      const int iw = i < 0 ? i + n : (i >= n ? i - n : i), i1 = iw + 1 == n ? 0 : iw + 1;
+      const int jw = j < 0 ? j + m : (j >= m ? j - m : j), j1 = jw + 1 == m ? 0 : jw + 1;
+      const double v00 = xc[(long)jw * n + iw], v10 = xc[(long)jw * n + i1], v01 = xc[(long)j1 * n + iw];
+      edge_prolong(v00, v10, sH, z);
+      if (c.in_y) edge_prolong(v10, v01, sD, z + NL);
+      if (c.in_y) edge_prolong(v00, v01, sV, z + 2 * NL);
+    } else if (c.exists) {
       const long J = g.joff + j;  // xc is the global (replicated) vertex vector
       const double v00 = xc[J * st + i];
       const double v10 = c.in_x ? xc[J * st + i + 1] : 0.0, v01 = c.in_y ? xc[(J + 1) * st + i] : 0.0;
@@ -338,7 +365,7 @@ __global__ __launch_bounds__(TraceTile<K>::NTHREADS) __attribute__((amdgpu_waves
         }
 #pragma unroll
         for (int q = 0; q < NT; q++) Zs[(plane_of<NL>(q) * H3 + (lj + 1)) * W3 + (li + 1)] = z2[q];
-        if (c.exists && li >= 2 && li < W2 - 2 && lj >= 2 && lj < H2 - 2 && jc < tr.jhi) store_corner<NL>(z_out, g, c, z2);
+        if (c.exists && c.own_x && li >= 2 && li < W2 - 2 && lj >= 2 && lj < H2 - 2 && jc < tr.jhi) store_corner<NL>(z_out, g, c, z2);
       }
     }
   }
@@ -352,7 +379,7 @@ __global__ __launch_bounds__(TraceTile<K>::NTHREADS) __attribute__((amdgpu_waves
       const int lj = idx / W2, li = idx - lj * W2;
       const int jc = j0 - 2 + lj;
       CornerInfo c = corner_info(g, tr, i0 - 2 + li, jc);
-      if (!(idx < TT::N2 && li >= 2 && li < W2 - 2 && lj >= 2 && lj < H2 - 2 && c.exists && jc < tr.jhi)) c.in_x = c.in_y = false;
+      if (!(idx < TT::N2 && li >= 2 && li < W2 - 2 && lj >= 2 && lj < H2 - 2 && c.exists && c.own_x && jc < tr.jhi)) c.in_x = c.in_y = false;
       load_corner<NL>(r, g, c, rr3[k]);
     }
   }
@@ -366,7 +393,7 @@ __global__ __launch_bounds__(TraceTile<K>::NTHREADS) __attribute__((amdgpu_waves
       if (li >= 2 && li < W2 - 2 && lj >= 2 && lj < H2 - 2) {
         const int jc = j0 - 2 + lj;
         const CornerInfo c = corner_info(g, tr, i0 - 2 + li, jc);
-        if (c.exists && jc < tr.jhi) {
+        if (c.exists && c.own_x && jc < tr.jhi) {
           double own[NT], y[3][NL], w[NT];
           lds_trace_stencil<K, W3, H3>(Zs, li + 1, lj + 1, c.in_x, c.in_y, c.below, c.left, T, own, y[0], y[1], y[2]);
 #pragma unroll

@@ -91,6 +91,31 @@ def test_periodic_imex_steps(hip_lib, k, nx, tableau):
     assert _rel(oQ, d.interpolate_velocity(Q0)) > 1e-3
 
 
+@pytest.mark.parametrize("k,nx", [(2, 16), (1, 18), (3, 16)])
+def test_periodic_steps_through_the_tiled_trace_preconditioner(hip_lib, k, nx):
+    """The LDS-tiled trace preconditioner on the periodic square (hdg_trace_tile.hpp: wrapped columns, the strip's own
+    opposite rows as ghost rows; nx >= 16): whole IMEX steps against the oracle, on a mesh of whole tiles and on one whose
+    last tile column is partial (18 columns: wrapped halo columns and masked surplus columns in the same tile)."""
+    from incompressibleeulerhdg_amd import _lib
+    from incompressibleeulerhdg_amd import timesteppers as tsm
+    from incompressibleeulerhdg_amd.mesh import PeriodicSquareMesh
+    from oracle import hdg_oracle as orc
+
+    d = orc.HDGDiscretisation(nx, k, periodic=True, L=L)
+    dt, nsteps = 0.25 * d.mesh.h, 2
+    Q0, p0 = _shear()
+    f = lambda t: (lambda x, y: (0.1 * np.cos(y) * np.cos(t), 0.2 * np.sin(x + y)))
+    o = orc.OracleHDGIMEX(d, dt, "imex_ssp2_332")
+    oQ, op = o.solve(d.interpolate_velocity(Q0), d.interpolate_pressure(p0), lambda t: d.interpolate_velocity(f(t)), nsteps * dt)
+    ts = tsm.IncompressibleEulerHDGIMEXSSP2_332(PeriodicSquareMesh(nx, nx, L=L), k, dt)
+    assert ts._engine.kernel_forms()["trace_precond"] == 1  # the tile kernels
+    Q, p = ts.solve(Q0, p0, None, f, nsteps * dt, fused=True)
+    lam = ts._engine.get_field(_lib.HDG_STATE_CURRENT, Q=False, p=False)[2]
+    assert _rel(Q.dat.data, oQ) < TOL and _rel(p.dat.data, op) < TOL and _rel(lam, o.lam) < TOL
+    sums, cnt = ts._engine.iteration_stats()
+    assert np.all((sums / np.maximum(cnt, 1))[1:] < 25)
+
+
 @pytest.mark.parametrize("k,nx", [(1, 4), (2, 4), (3, 4), (2, 6)])
 def test_periodic_continuous_space_tracer_operator_vorticity(hip_lib, k, nx):
     """CG_{k+1} on the periodic square (nx x ny corners, indices wrap): projection (common.py:119-122), tracer transport
