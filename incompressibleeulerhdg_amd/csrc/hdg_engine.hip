@@ -31,6 +31,7 @@
 #include "hdg_kernels.hpp"
 #include "hdg_schur_mfma.hpp"
 #include "hdg_trace_tile.hpp"
+#include "hdg_trace_tile3.hpp"
 #include "hdg_cg.hpp"
 #include "hdg_tables.hpp"
 #include "hdg_general.hpp"
@@ -2844,6 +2845,12 @@ struct Engine {
   // z = M r for the condensed system
   // LDS-tiled form of the two smoother applications (hdg_trace_tile.hpp): single rank, non-periodic structured mesh,
   // two Chebyshev steps.  HDG_TRACE_NO_TILE: the five row-stencil launches of before.
+  // form of the tile kernels: one thread per edge (hdg_trace_tile3.hpp) or one per corner (hdg_trace_tile.hpp); read per engine
+  // Measured (pressure solve, ms; corner form -> edge form): C3 6.24 -> 6.92, k = 3 at 512^2 3.16 -> 3.42, C2 1.03 -> 1.10 -- six
+  // instead of three waves per SIMD buy nothing where the corner form fits, the three-fold index arithmetic and the wider
+  // barriers cost; k = 4 at 512^2 (row-stencil kernels -> edge form) 5.32 -> 4.60.  Default: the edge form at k = 4 only.
+  int trace_tile3_env = std::getenv("HDG_TRACE_TILE3") ? std::atoi(std::getenv("HDG_TRACE_TILE3")) : -1;
+  bool tile3() const { return trace_tile3_env >= 0 ? trace_tile3_env != 0 : K >= 4; }
   static constexpr int TILE_HALO_R = 5;  // ghost rows of r the tiled preconditioner reads on a strip (pre: 3 computed + 2 halo)
   bool use_trace_tile() const {
     static const bool off = std::getenv("HDG_TRACE_NO_TILE") != nullptr;
@@ -2854,7 +2861,7 @@ struct Engine {
     // periodic square: the wrapped ghost rows play the neighbours' part (every tile reaches at most 3 columns / 5 rows beyond)
     static const bool per_ok = !std::getenv("HDG_TRACE_NO_TILE_PERIODIC");
     if (periodic && !(per_ok && g.nx >= 16 && g.ny >= 8)) return false;
-    return !off && fuse && nsm == 2 && cfg.trace_precond == 1 && !general && halo_on && K <= 3 &&
+    return !off && fuse && nsm == 2 && cfg.trace_precond == 1 && !general && halo_on && (K <= 3 || tile3()) &&
            (comm->size == 1 || (strips && g.ny >= TILE_HALO_R));
   }
   // vertex-grid correction of the trace preconditioner: mg_b[0] <- restriction of `res` (owned edges), one V-cycle, result in
@@ -2992,7 +2999,9 @@ struct Engine {
         const int nty_pre = (pre.jhi - pre.jlo + TT::TH - 1) / TT::TH, nty = (post.jhi - post.jlo + TT::TH - 1) / TT::TH;
         const int grid_pre = 8 * ((ntx * nty_pre + 7) / 8), grid = 8 * ((ntx * nty + 7) / 8);  // XCD-aware tile order (HDG_TILE_OF_BLOCK)
         tally(LC_TRACE_SMOOTH, 3 * bL());
-        k_trace_pre_tile<KK><<<grid_pre, TT::NTHREADS, 0, stream>>>(ntx, nty_pre, g, pre, pdt(), r, c0, c1, c2, ch_d, wL2);
+        typedef TraceTile3<KK> T3;
+        if (tile3()) k_trace_pre_tile3<KK><<<grid_pre, T3::NTHREADS, 0, stream>>>(ntx, nty_pre, g, pre, pdt(), r, c0, c1, c2, ch_d, wL2);
+        else k_trace_pre_tile<KK><<<grid_pre, TT::NTHREADS, 0, stream>>>(ntx, nty_pre, g, pre, pdt(), r, c0, c1, c2, ch_d, wL2);
         xp_ride_begin();  // the deferred half of the CG update: on the legs of the vertex-grid cycle ...
         if (!xp_riding && xp_at == 1) xp_launch(true);  // ... or underneath it on its own stream
         coarse_correction(wL2);
@@ -3006,7 +3015,13 @@ struct Engine {
           if (tile_part_cap < nblk * 5) { tile_part = dalloc(nblk * 5); tile_part_cap = nblk * 5; }
           part = tile_part;
         }
-        if (part)
+        if (tile3() && part)
+          k_trace_post_tile3<KK, true><<<grid, T3::NTHREADS, 0, stream>>>(ntx, nty, g, post, pdt(), ch_d, r, mg_x[0], std::sqrt(dt.elen[0]), std::sqrt(dt.elen[2]),
+                                                                          std::sqrt(dt.elen[1]), c0, c1, c2, z, w_out, part);
+        else if (tile3())
+          k_trace_post_tile3<KK, false><<<grid, T3::NTHREADS, 0, stream>>>(ntx, nty, g, post, pdt(), ch_d, r, mg_x[0], std::sqrt(dt.elen[0]), std::sqrt(dt.elen[2]),
+                                                                           std::sqrt(dt.elen[1]), c0, c1, c2, z, w_out, nullptr);
+        else if (part)
           k_trace_post_tile<KK, true><<<grid, TT::NTHREADS, 0, stream>>>(ntx, nty, g, post, pdt(), ch_d, r, mg_x[0], std::sqrt(dt.elen[0]), std::sqrt(dt.elen[2]),
                                                                          std::sqrt(dt.elen[1]), c0, c1, c2, z, w_out, part);
         else

@@ -138,11 +138,11 @@ def test_ghost_row_bookkeeping_self_check(hip_lib, tmp_path, nranks, k, nx, opts
     # the exchanges that were NOT skipped ran beside an interior launch (interior / boundary split on a second stream)
     m2 = re.search(r"\((\d+) of them beside an interior launch\)", logs[0])
     assert m2 and int(m2.group(1)) > 10, logs[0][-2000:]
-    # round 4: strips of >= 5 rows run the LDS-tiled trace preconditioner of the one-GPU path (k <= 3; one exchange of r, 5 rows
-    # deep, per CG iteration); shorter strips and k = 4 keep the row-stencil kernels
+    # round 4: strips of >= 5 rows run the LDS-tiled trace preconditioner of the one-GPU path (one exchange of r, 5 rows deep, per
+    # CG iteration; k = 4: the edge-per-thread form, hdg_trace_tile3.hpp); shorter strips keep the row-stencil kernels
     m3 = re.search(r"tiled trace preconditioner applications (\d+)", logs[0])
     assert m3, logs[0][-2000:]
-    assert (int(m3.group(1)) > 20) == (k <= 3 and nx // nranks >= 5), (m3.group(0), k, nx, nranks)
+    assert (int(m3.group(1)) > 20) == (nx // nranks >= 5), (m3.group(0), k, nx, nranks)
 
 
 def test_strip_partition_at_the_benchmark_size(hip_lib, tmp_path):
