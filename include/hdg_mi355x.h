@@ -224,8 +224,9 @@ int hdg_get_launch_stats(hdg_handle* h, long* calls, double* bytes, int reset);
  *   forms[0] edge lift (BDM projection / hybrid preconditioner): 0 gather form k_edge_lift, 1 paired form k_edge_lift_pair,
  *            2 matrix-core k_edge_lift_mfma, 3 assembled operator (general meshes);
  *   forms[1] advection operator: 0 per-thread k_adv_apply, 2 matrix-core k_adv_mfma, 3 general-mesh kernel k_g_adv;
- *   forms[2] trace preconditioner: 0 row-stencil kernels k_trace_smooth, 1 LDS-tiled k_trace_pre_tile / k_trace_post_tile,
- *            3 general meshes;
+ *   forms[2] trace preconditioner: 0 row-stencil kernels k_trace_smooth, 1 LDS-tiled k_trace_pre_tile / k_trace_post_tile (one
+ *            thread per grid corner: k <= 3), 2 the same tiles with one thread per edge, k_trace_pre_tile3 / k_trace_post_tile3
+ *            (k = 4), 3 general meshes;
  *   forms[3] local Schur kernels (back-substitution, pressure gradient, weak divergence): 0 per-thread, 2 matrix-core,
  *            3 assembled operators (general meshes). */
 #define HDG_N_KERNEL_FORMS 4

@@ -4418,7 +4418,7 @@ int hdg_get_kernel_forms(hdg_handle* h, int* forms) {
   if (!forms) throw std::string("forms is NULL");
   forms[0] = E.general ? 3 : (E.use_mfma_lift() ? 2 : (E.lift_pair() ? 1 : 0));
   forms[1] = E.general ? 3 : ((E.cfg.degree >= hdg::Engine::mfma_min_degree() && !E.periodic && !std::getenv("HDG_NO_MFMA_ADV")) ? 2 : 0);
-  forms[2] = E.general ? 3 : (E.use_trace_tile() ? 1 : 0);
+  forms[2] = E.general ? 3 : (E.use_trace_tile() ? (E.tile3() ? 2 : 1) : 0);
   forms[3] = E.general ? 3 : (E.use_mfma_schur() ? 2 : 0);
   HDG_API_END(h)
 }

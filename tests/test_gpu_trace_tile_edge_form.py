@@ -36,7 +36,7 @@ def test_edge_form_equals_the_other_form(hip_lib, k, nx, periodic, monkeypatch):
     for form in ("1", "0"):  # read when an engine is built
         monkeypatch.setenv("HDG_TRACE_TILE3", form)
         res[form] = _step(k, nx, periodic)
-    assert res["1"][4] == 1 and res["0"][4] == (1 if k <= 3 else 0)  # k = 4 without the edge form: the row-stencil kernels
+    assert res["1"][4] == 2 and res["0"][4] == (1 if k <= 3 else 0)  # k = 4 without the edge form: the row-stencil kernels
     for q in range(3):
         assert _rel(res["1"][q], res["0"][q]) < 1e-9, q
     assert np.all(np.abs(res["1"][3][1:] - res["0"][3][1:]) <= 1.0), (res["1"][3], res["0"][3])
@@ -48,7 +48,7 @@ def test_edge_form_is_the_default_at_degree_four_and_matches_the_oracle(hip_lib,
     monkeypatch.delenv("HDG_TRACE_TILE3", raising=False)
     k, nx = 4, 8
     Q, p, lam, its, form = _step(k, nx, False, nsteps=2)
-    assert form == 1
+    assert form == 2  # hdg_get_kernel_forms: tiles, one thread per edge
     d = orc.HDGDiscretisation(nx, k)
     tg = orc.TaylorGreen(d)
     o = orc.OracleHDGIMEX(d, 0.25 / nx, "imex_ssp2_332")
