@@ -1774,7 +1774,7 @@ struct Engine {
   // second stage of a reduction whose per-workgroup partials a kernel left in part[block * nout + q] (the tile kernels of the
   // trace preconditioner), summed over the ranks; the results stay in d_res
   void reduce_parts_allreduce(int nblocks, int nout, const double* part) {
-    k_reduce_parts<<<nout, 256, 0, stream>>>(nblocks, nout, part, d_res);
+    k_reduce_parts<<<nout, 256, 0, stream>>>(nblocks, nout, part, d_res, nullptr, 1);
     comm->allreduce_sum(d_res, nout, stream);
     n_reduce++;
   }
@@ -3030,9 +3030,8 @@ struct Engine {
           k_trace_post_tile<KK, false><<<grid, TT::NTHREADS, 0, stream>>>(ntx, nty, g, post, pdt(), ch_d, r, mg_x[0], std::sqrt(dt.elen[0]), std::sqrt(dt.elen[2]),
                                                                           std::sqrt(dt.elen[1]), c0, c1, c2, z, w_out, nullptr);
         if (part) {
-          tally(LC_OTHER, 0.0);
           if (defer_tile_reduce) tile_nblk_deferred = (int)nblk;  // one rank: summed by the kernel that forms the CG scalars
-          else reduce_parts_allreduce((int)nblk, 5, part);        // second reduction stage (+ the all-reduce across ranks) -> d_res
+          else { tally(LC_OTHER, 0.0); reduce_parts_allreduce((int)nblk, 5, part); }  // second reduction stage (+ the all-reduce across ranks) -> d_res
           *dots_out = true;
         }
       };

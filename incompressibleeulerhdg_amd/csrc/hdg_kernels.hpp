@@ -2490,11 +2490,13 @@ __global__ __launch_bounds__(HDG_DOT_BLOCK) void k_multidot(long N, const double
 }
 // hres != nullptr: the result goes to pinned host memory as well (the host reads it after a stream / event synchronisation:
 // no copy kernel, which costs 8 us on the stream)
+// transposed != 0: part[k * nblocks + b] (the tile kernels of the trace preconditioner: coalesced for the second stage)
 __global__ void k_reduce_parts(int nblocks, int nv, const double* __restrict__ part, double* __restrict__ res,
-                               double* __restrict__ hres = nullptr) {
+                               double* __restrict__ hres = nullptr, int transposed = 0) {
   const int k = blockIdx.x;
   double acc = 0.0;
-  for (int b = threadIdx.x; b < nblocks; b += blockDim.x) acc += part[(long)b * nv + k];
+  if (transposed) for (int b = threadIdx.x; b < nblocks; b += blockDim.x) acc += part[(long)k * nblocks + b];
+  else for (int b = threadIdx.x; b < nblocks; b += blockDim.x) acc += part[(long)b * nv + k];
   __shared__ double sm[4];
   const double s = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
@@ -2511,9 +2513,9 @@ __global__ void k_reduce_parts(int nblocks, int nv, const double* __restrict__ p
 __global__ __launch_bounds__(1024) void k_cg_sr_reduce_scalars(int nblocks, const double* __restrict__ part, double* __restrict__ res,
                                                                double* __restrict__ sc, double nn, int first, double* __restrict__ hsc) {
   double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-  for (int b = threadIdx.x; b < nblocks; b += 1024) {
+  for (int b = threadIdx.x; b < nblocks; b += 1024) {  // part[q * nblocks + tile]: as the tile kernels leave it
 #pragma unroll
-    for (int q = 0; q < 5; q++) acc[q] += part[(long)b * 5 + q];
+    for (int q = 0; q < 5; q++) acc[q] += part[(long)q * nblocks + b];
   }
   __shared__ double sm[16][5];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;

@@ -431,7 +431,7 @@ __global__ __launch_bounds__(TraceTile<K>::NTHREADS) __attribute__((amdgpu_waves
     if (threadIdx.x < 5) {
       double sv = 0.0;
       for (int w2 = 0; w2 < TT::NTHREADS / 64; w2++) sv += sm[w2][threadIdx.x];
-      part[(long)tile_v * 5 + threadIdx.x] = sv;
+      part[(long)threadIdx.x * (ntx * nty) + tile_v] = sv;  // [inner product][tile]
     }
   }
 }
