@@ -2896,6 +2896,21 @@ struct Engine {
   // instead of k_reduce_parts + k_cg_sr_scalars)
   bool defer_tile_reduce = false;
   int tile_nblk_deferred = 0;
+  // Experiment (HDG_CG_FUSED_RUPDATE=1, off; trace_cg_sr, one rank, corner-form tiles, non-periodic): the residual half of the
+  // update (s, r) inside the next pre tile kernel (k_trace_pre_tile<K, true>), which writes into second buffers; ru_flush() runs
+  // it as its own launch instead.  Measured (pressure solve, ms; own launch -> fused): C3 6.17 -> 6.47, k = 3 at 512^2
+  // 3.15 -> 3.30, C2 0.99 -> 1.05: the tile kernel loads r, w and s with its halo (1.9 x) at a third of the streaming rate --
+  // dearer than the 54 us launch it saves.
+  bool cg_no_fused_r = std::getenv("HDG_CG_FUSED_RUPDATE") == nullptr;  // read per engine
+  double *cg_r2 = nullptr, *cg_s2 = nullptr;
+  bool ru_pending = false, ru_fused = false;
+  double *ru_r = nullptr, *ru_s = nullptr, *ru_r_alt = nullptr, *ru_s_alt = nullptr;
+  void ru_flush() {
+    if (!ru_pending) return;
+    ru_pending = false;
+    k_cg_sr_update_r<<<vec_blocks(NLv), 256, 0, stream>>>(NLv, d_cgs, cg_Ap, ru_s, ru_r);
+  }
+  bool ru_fusable() const { return comm->size == 1 && !periodic && !general && !tile3() && use_trace_tile(); }
   // trace_cg_sr with the tile preconditioner: the half of the update nothing reads before the next update (p, x) runs on
   // a second stream underneath the vertex-grid V-cycle, whose launches are latency-bound and leave HBM idle
   hipStream_t xstream = nullptr;
@@ -2974,6 +2989,7 @@ struct Engine {
   }
   bool trace_precond(const double* r, double* z, double* w_out = nullptr, bool* dots_out = nullptr) {
     if (dots_out) *dots_out = false;
+    if (ru_pending && !ru_fusable()) ru_flush();
     if (cfg.trace_precond == 0) {
       zero(z, NLv);
       trace_cheb(r, ch_d, z, 0.0, 1.0);
@@ -3003,7 +3019,12 @@ struct Engine {
         tally(LC_TRACE_SMOOTH, 3 * bL());
         typedef TraceTile3<KK> T3;
         if (tile3()) k_trace_pre_tile3<KK><<<grid_pre, T3::NTHREADS, 0, stream>>>(ntx, nty_pre, g, pre, pdt(), r, c0, c1, c2, ch_d, wL2);
-        else k_trace_pre_tile<KK><<<grid_pre, TT::NTHREADS, 0, stream>>>(ntx, nty_pre, g, pre, pdt(), r, c0, c1, c2, ch_d, wL2);
+        else if (ru_pending) {  // (ru_fusable(): checked on entry) with the residual half of the CG update; r' lands in the second buffer
+          k_trace_pre_tile<KK, true><<<grid_pre, TT::NTHREADS, 0, stream>>>(ntx, nty_pre, g, pre, pdt(), ru_r, c0, c1, c2, ch_d, wL2, d_cgs, cg_Ap, ru_s,
+                                                                            ru_s_alt, ru_r_alt);
+          r = ru_r_alt;
+          ru_pending = false; ru_fused = true;
+        } else k_trace_pre_tile<KK><<<grid_pre, TT::NTHREADS, 0, stream>>>(ntx, nty_pre, g, pre, pdt(), r, c0, c1, c2, ch_d, wL2);
         xp_ride_begin();  // the deferred half of the CG update: on the legs of the vertex-grid cycle ...
         if (!xp_riding && xp_at == 1) xp_launch(true);  // ... or underneath it on its own stream
         coarse_correction(wL2);
@@ -3236,7 +3257,7 @@ struct Engine {
   int trace_cg_sr(double* b, double* x, double rtol, int maxit, bool strict) {
     const bool no_split = cg_no_split, no_fused = cg_no_fused_scalars;
     auto leave = [&]() {  // a deferred p / x update left over at the exit is the step beyond the tested iterate: dropped
-      xp_pending = false;
+      xp_pending = false; ru_pending = false; ru_fused = false;
       defer_tile_reduce = false; tile_nblk_deferred = 0;
       if (xp_inflight) { xp_inflight = false; (void)hipStreamWaitEvent(stream, ev_x1, 0); }
     };
@@ -3257,6 +3278,9 @@ struct Engine {
     trace_apply(x, b, 1.0, -1.0, cg_r);  // r = b - T x
     if (tr_one_nn < 0) tr_one_nn = dot(NLv, tr_one, tr_one, KL);
     if (!cg_s) cg_s = dalloc(NLv);
+    const bool fuse_r = split && !cg_no_fused_r && ru_fusable();
+    if (fuse_r && !cg_r2) { cg_r2 = dalloc(NLv); cg_s2 = dalloc(NLv); }
+    double *r_cur = cg_r, *s_cur = cg_s, *r_alt = cg_r2, *s_alt = cg_s2;  // (r_cur == cg_r on entry: r = b - T x above)
     const int nvb = vec_blocks(NLv);
     HIPCHECK(hipMemsetAsync(d_cgs, 0, sizeof(double) * 8, stream));
     double norm0 = -1.0;
@@ -3285,20 +3309,24 @@ struct Engine {
     static const double floor_c = std::getenv("HDG_CG_FLOOR_C") ? std::atof(std::getenv("HDG_CG_FLOOR_C")) : 32.0;
     auto replace_residual = [&](const char* why, double at, bool is_breakdown) {
       xp_launch(false);  // the true residual needs the current iterate
+      ru_pending = false;  // (the pending residual update is overwritten; the restart needs no s)
       if (drifts >= 2) throw NotConverged{std::string("trace CG: ") + why + " after two residual replacements that confirmed a drifted recurrence"};
       replaced++;
       trigger_nrm = at; trigger_breakdown = is_breakdown;
       ev_cg_replacements++;
       if (debug_cg()) fprintf(stderr, "[cg] it %d: %s at |z|/|z0| %.3e: residual replacement %d\n", its, why, at / norm0, replaced);
       HIPCHECK(hipMemsetAsync(d_cgs + 6, 0, sizeof(double), stream));
-      trace_apply(x, b, 1.0, -1.0, cg_r);  // the true residual of the current iterate
+      trace_apply(x, b, 1.0, -1.0, r_cur);  // the true residual of the current iterate
       restart = true; true_residual = true;
       best = 1e300; since_best = 0;
     };
     while (true) {
       bool have_dots = false;
-      if (!trace_precond(cg_r, cg_z, cg_Ap, &have_dots)) trace_apply(cg_z, nullptr, 0.0, 1.0, cg_Ap);  // w = T z
-      if (!have_dots) multidot(NLv, cg_z, {tr_one, cg_r, cg_z, cg_Ap}, nullptr, KL, true);  // (z,n), (z,r), (z,z), (z,w), (n,r) -> d_res
+      ru_fused = false;
+      const bool have_w = trace_precond(r_cur, cg_z, cg_Ap, &have_dots);
+      if (ru_fused) { std::swap(r_cur, r_alt); std::swap(s_cur, s_alt); ru_fused = false; }  // the pre kernel left r', s' in the second buffers
+      if (!have_w) trace_apply(cg_z, nullptr, 0.0, 1.0, cg_Ap);  // w = T z
+      if (!have_dots) multidot(NLv, cg_z, {tr_one, r_cur, cg_z, cg_Ap}, nullptr, KL, true);  // (z,n), (z,r), (z,z), (z,w), (n,r) -> d_res
       tally(LC_OTHER, 0.0);
       tally(LC_VEC, bL() * 11);  // k_cg_sr_update: reads z, n, w, p, s, x, r; writes p, s, x, r
       if (have_dots && tile_nblk_deferred > 0) {
@@ -3311,13 +3339,14 @@ struct Engine {
       HIPCHECK(hipEventRecord(cg_ev, stream));
       if (split) {
         // r first (the next preconditioner application waits for it); p and x when that application reaches its V-cycle
-        k_cg_sr_update_r<<<nvb, 256, 0, stream>>>(NLv, d_cgs, cg_Ap, cg_s, cg_r);
+        if (fuse_r) { ru_pending = true; ru_r = r_cur; ru_s = s_cur; ru_r_alt = r_alt; ru_s_alt = s_alt; }  // inside the next pre kernel
+        else k_cg_sr_update_r<<<nvb, 256, 0, stream>>>(NLv, d_cgs, cg_Ap, s_cur, r_cur);
         xp_pending = true; xp_x = x;
         if (xp_at == 0 && xp_mode != 1) xp_launch(true);
       } else
-        k_cg_sr_update<<<nvb, 256, 0, stream>>>(NLv, d_cgs, cg_z, tr_one, cg_Ap, cg_p, cg_s, x, cg_r);
-      fl.set(cg_s, restart ? fl.get(cg_Ap) : std::min(fl.get(cg_s), fl.get(cg_Ap)));
-      fl.set(cg_r, std::min(fl.get(cg_r), fl.get(cg_s)));
+        k_cg_sr_update<<<nvb, 256, 0, stream>>>(NLv, d_cgs, cg_z, tr_one, cg_Ap, cg_p, s_cur, x, r_cur);
+      fl.set(s_cur, restart ? fl.get(cg_Ap) : std::min(fl.get(s_cur), fl.get(cg_Ap)));
+      fl.set(r_cur, std::min(fl.get(r_cur), fl.get(s_cur)));
       fl.set(x, 0);
       const bool was_true = true_residual;
       restart = false; true_residual = false;
