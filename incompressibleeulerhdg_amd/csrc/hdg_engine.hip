@@ -2932,9 +2932,11 @@ struct Engine {
     xp_done = 0; xp_riding = false;
     if (!xp_pending || xp_mode != 1 || periodic || general || mg_n.empty()) return;
     static const bool fuse_legs = !std::getenv("HDG_MG_NO_FUSE");
-    if (!fuse_legs || mg_distributed()) return;
+    if (!fuse_legs) return;
+    // strips: the finest level is distributed (vcycle_distributed_top launches its legs itself); the replicated levels carry the update
+    const size_t l0 = mg_distributed() ? 1 : 0;
     xp_wsum = 0.0;
-    for (size_t l = 0; l + 1 < mg_n.size() && mg_n[l] > 32 && (mg_n[l] & 1) == 0; l++) xp_wsum += 2.0 * (l == 0 ? xp_w0 : 1.0);
+    for (size_t l = l0; l + 1 < mg_n.size() && mg_n[l] > 32 && (mg_n[l] & 1) == 0; l++) xp_wsum += 2.0 * (l == 0 ? xp_w0 : 1.0);
     xp_riding = xp_wsum > 0.0;
   }
   SideXP xp_side_slice(int lev, int nt, int& extra_rows) {
@@ -3263,7 +3265,7 @@ struct Engine {
     };
     try {
       defer_tile_reduce = comm->size == 1 && !no_fused;
-      const int its = trace_cg_sr_body(b, x, rtol, maxit, strict, !no_split && comm->size == 1 && use_trace_tile() && NLv * 8L >= split_min_bytes);
+      const int its = trace_cg_sr_body(b, x, rtol, maxit, strict, !no_split && use_trace_tile() && NLv * 8L >= split_min_bytes);
       leave();
       return its;
     } catch (...) {
