@@ -73,7 +73,7 @@ class hdg_config(C.Structure):
 
 def build_library(force=False, verbose=False):
     """Compile the HIP engine for gfx950 into the package directory (in-tree, travels with gpurun)."""
-    srcs = [SRC, HEADER] + [os.path.join(_HERE, "csrc", f) for f in ("hdg_kernels.hpp", "hdg_schur_mfma.hpp", "hdg_tables.hpp", "hdg_comm.hpp", "hdg_cg.hpp", "hdg_general.hpp", "hdg_general_kernels.hpp", "hdg_trace_tile.hpp", "hdg_trace_tile3.hpp", "hdg_amg.hpp")]
+    srcs = [SRC, HEADER] + [os.path.join(_HERE, "csrc", f) for f in ("hdg_kernels.hpp", "hdg_schur_mfma.hpp", "hdg_tables.hpp", "hdg_comm.hpp", "hdg_cg.hpp", "hdg_general.hpp", "hdg_general_kernels.hpp", "hdg_trace_tile.hpp", "hdg_trace_tile3.hpp", "hdg_side_rows.hpp", "hdg_amg.hpp")]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -2953,11 +2953,7 @@ struct Engine {
     extra_rows = (int)((blocks + nt - 1) / nt);
     return sj;
   }
-  // interleaving of side rows and tile rows of a leg launch (HDG_P1_SIDE_JOB)
-  static int xp_period(int nt, int extra) {
-    if (extra <= 0) return 2;
-    return extra <= nt ? std::max(2, (nt + extra) / extra) : -std::max(2, (nt + extra) / nt);
-  }
+  static int xp_period(int nt, int extra) { return side_row_period(nt, extra); }  // hdg_side_rows.hpp
   void xp_launch(bool overlap) {
     if (!xp_pending) return;
     xp_pending = false;

@@ -18,6 +18,7 @@
 // Facet coupling is done by neighbour GATHER (owner computes), never by atomics, so results are
 // bitwise reproducible.
 #pragma once
+#include "hdg_side_rows.hpp"
 #include <hip/hip_runtime.h>
 
 namespace hdg {
@@ -2513,6 +2514,7 @@ __global__ void k_reduce_parts(int nblocks, int nv, const double* __restrict__ p
 __global__ __launch_bounds__(1024) void k_cg_sr_reduce_scalars(int nblocks, const double* __restrict__ part, double* __restrict__ res,
                                                                double* __restrict__ sc, double nn, int first, double* __restrict__ hsc) {
   double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
   for (int b = threadIdx.x; b < nblocks; b += 1024) {  // part[q * nblocks + tile]: as the tile kernels leave it
 #pragma unroll
     for (int q = 0; q < 5; q++) acc[q] += part[(long)q * nblocks + b];
@@ -2884,24 +2886,14 @@ __device__ __forceinline__ void side_xp(const SideXP& sj, long blk, long nblk) {
     as2(sj.x)[i] = fma2(alpha, pv, xv);
   }
 }
-// Rows of a leg launch with `extra` side rows: the less numerous kind of row (side rows for period > 0, tile rows for
-// period < 0) takes the last row of every group of |period| rows until it is used up, so that the short-lived side workgroups
-// are dispatched in between the tiles instead of behind them (the finest level has twice as many tiles as the chip has
-// slots for).  by = the tile row of a workgroup that has one.
+// by = the tile row of a workgroup that has one; side rows do their share of the side job and leave (hdg_side_rows.hpp)
 #define HDG_P1_SIDE_JOB                                                                                              \
-  int by = (int)blockIdx.y;                                                                                          \
-  if (extra > 0) {                                                                                                   \
-    const int per_ = period < 0 ? -period : period;                                                                  \
-    const int nminor_ = period < 0 ? (int)gridDim.y - extra : extra;                                                 \
-    const int q_ = by / per_, rem_ = by - q_ * per_;                                                                 \
-    const bool minor_ = rem_ == per_ - 1 && q_ < nminor_;                                                            \
-    const int idx_ = minor_ ? q_ : by - (q_ < nminor_ ? q_ : nminor_);                                               \
-    if ((period < 0) != minor_) {                                                                                    \
-      side_xp(sj, (long)idx_ * gridDim.x + blockIdx.x, (long)extra * gridDim.x);                                     \
-      return;                                                                                                        \
-    }                                                                                                                \
-    by = idx_;                                                                                                       \
-  }
+  const SideRow srow_ = side_row_of((int)blockIdx.y, (int)gridDim.y, extra, period);                                 \
+  if (srow_.side) {                                                                                                  \
+    side_xp(sj, (long)srow_.idx * gridDim.x + blockIdx.x, (long)extra * gridDim.x);                                  \
+    return;                                                                                                          \
+  }                                                                                                                  \
+  const int by = srow_.idx;
 // region-local stencil: (gi, gj) global vertex, (li, lj) local; false if a neighbour inside the domain lies
 // outside the loaded region (the point is then part of the garbage ring and is skipped).
 // The diagonal is 4 (interior), 2 (boundary edge) or 1 (corner): its reciprocal is exact, so multiplying by

@@ -332,6 +332,23 @@ def test_general_mesh_host_side_invariants(tmp_path, k, level):
     assert abs(f("cg_volume") - m.volume) < 1e-11
 
 
+def test_side_rows_of_a_leg_launch_cover_every_row_once(tmp_path):
+    """csrc/hdg_side_rows.hpp (plain C++, compiled here with g++): the interleaving of tile rows and side rows of a V-cycle leg
+    launch that carries a share of the condensed CG's p / x update visits every tile row and every side row exactly once, for
+    1..70 tile rows and 0..400 side rows (the GPU tests cover a handful of these through whole steps)."""
+    import shutil
+    import subprocess
+
+    gxx = shutil.which("g++")
+    if gxx is None:
+        pytest.skip("no g++")
+    exe = tmp_path / "side_rows_check"
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "host", "side_rows_check.cpp")
+    subprocess.run([gxx, "-std=c++17", "-O1", "-o", str(exe), src], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    assert out.startswith("ok 28070"), out
+
+
 def test_unit_disk_mesh_numbering_independent_invariants():
     """UnitDiskMesh (driver.py:184-185) is restated from memory of Firedrake's utility mesh on both the product and the
     oracle side -- no reference fixture covers its numbering or coordinates (parity unpinned).  What any correct
