@@ -19,7 +19,7 @@ for r in csv.DictReader(open(f[0])):
     name = r["Kernel_Name"].split("(")[0].replace("void hdg::", "").replace("hdg::", "")
     acc[name][r["Counter_Name"]] += float(r["Counter_Value"]); n[name].add(r["Dispatch_Id"])
 keys = sorted({c for v in acc.values() for c in v})
-want = ("k_adv_apply<2, true>", "k_edge_lift<2, false, 2, true>", "k_trace_post_tile<2, true>", "k_trace_pre_tile<2>", "k_cg_sr_update", "k_gs_update<32, true, double>", "k_adv_apply<2, false>")
+want = ("k_adv_apply<2, true>", "k_edge_lift<2, false, 2, true>", "k_trace_post_tile<2, true>", "k_trace_pre_tile<2>", "k_trace_pre_tile<2, false>", "k_cg_sr_update", "k_cg_sr_update_r", "k_p1_down<2>", "k_p1_up<2>", "k_edge_lift_pair<2, false, 2, false>", "k_gs_update<32, true, double>", "k_adv_apply<2, false>")
 for name in want:
     if name in acc:
         print(name, "launches", len(n[name]), " ".join(f"{c}={acc[name][c] / len(n[name]):.4g}" for c in keys))
