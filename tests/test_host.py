@@ -332,6 +332,26 @@ def test_general_mesh_host_side_invariants(tmp_path, k, level):
     assert abs(f("cg_volume") - m.volume) < 1e-11
 
 
+def test_committed_pmc_traffic_belongs_to_the_committed_kernel_sources():
+    """profiles/pmc_traffic.json (HBM-side bytes per launch from the FETCH_SIZE / WRITE_SIZE passes; bench.py prints them as
+    `roofline.traffic`) carries the hash of every kernel / engine source it was measured on: it must be the hash of the sources
+    in the tree, or the bench line would report no traffic (and the profile set under profiles/ would be of other code)."""
+    import json
+    import sys
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+        t = json.load(f)
+    assert t["csrc_sha16"] == bench.csrc_sha16(), (t["tag"], "re-collect with tools/collect_profiles.sh after changing csrc/")
+    tag = t["tag"]
+    for name in (f"{tag}_bench_c3.json", f"{tag}_c3_kernel_stats.csv", f"{tag}_c3_pmc_fetch.csv", f"{tag}_c3_pmc_write.csv"):
+        assert os.path.exists(os.path.join(ROOT, "profiles", name)), name
+    calib = t["calibration"]  # the stream triad: FETCH_SIZE counts half of the bytes on gfx950, WRITE_SIZE all of them
+    assert abs(calib["measured_factor_fetch"] - 2.0) < 0.01 and abs(calib["measured_factor_write"] - 1.0) < 0.01
+
+
 def test_side_rows_of_a_leg_launch_cover_every_row_once(tmp_path):
     """csrc/hdg_side_rows.hpp (plain C++, compiled here with g++): the interleaving of tile rows and side rows of a V-cycle leg
     launch that carries a share of the condensed CG's p / x update visits every tile row and every side row exactly once, for
