@@ -2778,6 +2778,34 @@ struct Engine {
     allocs.erase(std::find(allocs.begin(), allocs.end(), (void*)MT));
     tail_M = M; tail_lev = lev; tail_pitch = pitch;
   }
+  // periodic vertex grids: column c of the tail's matrix = the per-level V-cycle from the first level with n <= 32 applied to the
+  // c-th unit vector (n^2 <= 1024 columns of ~45 small launches each, once per engine: a few tenths of a second)
+  bool building_tail = false;
+  void build_dense_tail_periodic() {
+    static const bool off = std::getenv("HDG_MG_NO_DENSE_TAIL") != nullptr || std::getenv("HDG_MG_NO_TAIL") != nullptr || std::getenv("HDG_MG_NO_FUSE") != nullptr;
+    if (off || !periodic || mg_n.empty()) return;
+    int lev = 0;
+    while (lev < (int)mg_n.size() && mg_n[lev] > 32) lev++;
+    if (lev == 0 || lev >= (int)mg_n.size() - 1) return;  // no level above the tail (nothing fused), or a single level: nothing to gain
+    const int n = mg_n[lev], N = n * n, pitch = (N + 1) & ~1;
+    if (N > 1024) return;
+    double* MT = dalloc((long)N * pitch);
+    double* M = dalloc((long)N * pitch);
+    building_tail = true;
+    const double one = 1.0;
+    for (int c = 0; c < N; c++) {
+      zero(mg_b[lev], N);
+      HIPCHECK(hipMemcpyAsync(mg_b[lev] + c, &one, sizeof(double), hipMemcpyHostToDevice, stream));
+      vcycle_periodic(lev);
+      HIPCHECK(hipMemcpyAsync(MT + (long)c * pitch, mg_x[lev], sizeof(double) * N, hipMemcpyDeviceToDevice, stream));
+    }
+    building_tail = false;
+    k_transpose_sq<<<dim3((N + 255) / 256, N), 256, 0, stream>>>(N, pitch, MT, M);
+    HIPCHECK(hipStreamSynchronize(stream));
+    HIPCHECK(hipFree(MT));
+    allocs.erase(std::find(allocs.begin(), allocs.end(), (void*)MT));
+    tail_M = M; tail_lev = lev; tail_pitch = pitch;
+  }
   // ---- strip partition: the finest vertex grid stays distributed, the rest of the V-cycle is replicated.
   // The replicated cycle (every rank gathers the whole (nx+1)^2 right-hand side, 8.4 MB at C3, and runs every level)
   // does not shrink with the number of ranks.  Here each rank keeps its ny+1 vertex rows of level 0:
@@ -2834,6 +2862,28 @@ struct Engine {
         k_p1p_rbgs<<<grid, 64, 0, stream>>>(n, mg_x[lev], mg_b[lev], reverse ? 0 : 1);
       }
     };
+    // second half of round 4: the fused LDS-tile legs (k_p1_down / k_p1_up, PER = true: wrapped loads, every vertex interior) for
+    // n > 32 and the tail n <= 32 as one dense product (build_dense_tail_periodic), as on the unit square; the legs carry the
+    // p / x half of the CG update as side jobs there too.  HDG_MG_NO_FUSE / HDG_MG_NO_DENSE_TAIL: the per-level kernels below.
+    static const bool fuse_legs = !std::getenv("HDG_MG_NO_FUSE");
+    if (tail_M && lev == tail_lev) {
+      const int N = n * n;
+      tally(LC_MG, 16.0 * N);
+      k_p1_dense_tail<<<(N + 3) / 4, 256, 0, stream>>>(N, tail_pitch, tail_M, mg_b[lev], mg_x[lev]);
+      return;
+    }
+    if (fuse_legs && nsw == 2 && n > 32 && lev + 1 < (int)mg_n.size() && !building_tail) {
+      const int nt = (n + HDG_P1_TS - 1) / HDG_P1_TS;
+      int extra = 0;
+      SideXP sj = xp_side_slice(lev, nt, extra);
+      tally(LC_MG, 8.0 * nv * 2.25);
+      k_p1_down<2, true><<<dim3(nt, nt + extra), HDG_P1_THREADS, 0, stream>>>(n, mg_b[lev], mg_r[lev], mg_b[lev + 1], 0, extra, xp_period(nt, extra), sj);
+      vcycle_periodic(lev + 1);
+      sj = xp_side_slice(lev, nt, extra);
+      tally(LC_MG, 8.0 * nv * 3.25);
+      k_p1_up<2, true><<<dim3(nt, nt + extra), HDG_P1_THREADS, 0, stream>>>(n, mg_x[lev + 1], mg_b[lev], mg_r[lev], mg_x[lev], 0, extra, xp_period(nt, extra), sj);
+      return;
+    }
     zero(mg_x[lev], nv);
     if (lev == (int)mg_n.size() - 1) { sweeps(ncoarse, false); sweeps(ncoarse, true); return; }
     sweeps(nsw, false);
@@ -2930,7 +2980,7 @@ struct Engine {
   bool xp_riding = false;
   void xp_ride_begin() {
     xp_done = 0; xp_riding = false;
-    if (!xp_pending || xp_mode != 1 || periodic || general || mg_n.empty()) return;
+    if (!xp_pending || xp_mode != 1 || general || mg_n.empty()) return;
     static const bool fuse_legs = !std::getenv("HDG_MG_NO_FUSE");
     if (!fuse_legs) return;
     // strips: the finest level is distributed (vcycle_distributed_top launches its legs itself); the replicated levels carry the update
@@ -3112,7 +3162,7 @@ struct Engine {
         n /= 2;
       }
     }
-    if (cfg.trace_precond == 1) build_dense_tail();
+    if (cfg.trace_precond == 1) { build_dense_tail(); build_dense_tail_periodic(); }
     psets.push_back(PSet{dt, 0.0, 0.0, cfg.tau});
     estimate_cheb(0);
     use_pset(0);

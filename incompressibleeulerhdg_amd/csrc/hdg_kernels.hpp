@@ -2894,13 +2894,21 @@ __device__ __forceinline__ void side_xp(const SideXP& sj, long blk, long nblk) {
     return;                                                                                                          \
   }                                                                                                                  \
   const int by = srow_.idx;
+__device__ __forceinline__ int pw2(int a, int n) { return a < 0 ? a + n : (a >= n ? a - n : a); }  // periodic index (|shift| < n)
 // region-local stencil: (gi, gj) global vertex, (li, lj) local; false if a neighbour inside the domain lies
 // outside the loaded region (the point is then part of the garbage ring and is skipped).
 // The diagonal is 4 (interior), 2 (boundary edge) or 1 (corner): its reciprocal is exact, so multiplying by
 // `inv` is bit-identical to the division in k_p1_rbgs.
-template <int W>
+template <int W, bool PER = false>
 __device__ __forceinline__ bool p1_stencil_tile(const double* X, int n, int gi, int gj, int li, int lj, double& diag,
                                                 double& off) {
+  if (PER) {  // periodic n x n grid: every vertex is interior (same order of the four terms as k_p1p_rbgs / k_p1p_residual)
+    diag = 4.0;
+    off = 0.0;
+    if (li == 0 || li == W - 1 || lj == 0 || lj == W - 1) return false;
+    off = X[lj * W + li - 1] + X[lj * W + li + 1] + X[(lj - 1) * W + li] + X[(lj + 1) * W + li];
+    return true;
+  }
   const double wx = (gj == 0 || gj == n) ? 0.5 : 1.0;
   const double wy = (gi == 0 || gi == n) ? 0.5 : 1.0;
   diag = 0.0;
@@ -2913,16 +2921,16 @@ __device__ __forceinline__ bool p1_stencil_tile(const double* X, int n, int gi, 
   return true;
 }
 // 2 nsw half sweeps; each thread owns the q-th vertex of the active colour (W even: W/2 per row and colour)
-template <int W>
+template <int W, bool PER = false>
 __device__ __forceinline__ void p1_tile_sweeps(double* X, const double* B, int n, int gi0, int gj0, int nsw, bool reverse) {
   for (int hs = 0; hs < 2 * nsw; hs++) {
     const int colour = ((hs & 1) == 0) ? (reverse ? 1 : 0) : (reverse ? 0 : 1);
     for (int q = threadIdx.x; q < W * W / 2; q += HDG_P1_THREADS) {
       const int lj = q / (W / 2), li = 2 * (q - lj * (W / 2)) + ((colour + gi0 + gj0 + lj) & 1);
       const int gi = gi0 + li, gj = gj0 + lj;
-      if (gi < 0 || gj < 0 || gi > n || gj > n) continue;
+      if (!PER && (gi < 0 || gj < 0 || gi > n || gj > n)) continue;
       double diag, off;
-      if (p1_stencil_tile<W>(X, n, gi, gj, li, lj, diag, off)) {
+      if (p1_stencil_tile<W, PER>(X, n, gi, gj, li, lj, diag, off)) {
         const double inv = diag == 4.0 ? 0.25 : (diag == 2.0 ? 0.5 : 1.0 / diag);
         X[lj * W + li] = (B[lj * W + li] + off) * inv;
       }
@@ -2931,34 +2939,38 @@ __device__ __forceinline__ void p1_tile_sweeps(double* X, const double* B, int n
   }
 }
 // down leg: x = 0, nsw sweeps on A x = b, r = b - A x, bc = R r (coarse right-hand side); x is stored to xpre
-template <int NSW>
+// PER: the doubly periodic n x n vertex grid (indices wrap; the coarse grid is n/2 x n/2; same expressions as k_p1p_*)
+template <int NSW, bool PER = false>
 __global__ __launch_bounds__(HDG_P1_THREADS) void k_p1_down(int n, const double* __restrict__ b, double* __restrict__ xpre,
                                                             double* __restrict__ bc, int jt0 = 0, int extra = 0, int period = 2, SideXP sj = SideXP{}) {
   constexpr int H = 2 * NSW + 2, W = HDG_P1_TS + 2 * H;
   __shared__ double X[W * W];
   __shared__ double B[W * W];
   HDG_P1_SIDE_JOB
-  const int st = n + 1;
+  const int st = PER ? n : n + 1, last = PER ? n - 1 : n;  // row pitch, last vertex index
   const int i0 = blockIdx.x * HDG_P1_TS, j0 = (by + jt0) * HDG_P1_TS, gi0 = i0 - H, gj0 = j0 - H;  // jt0: first tile row of this launch
   for (int p = threadIdx.x; p < W * W; p += HDG_P1_THREADS) {
     const int lj = p / W, li = p - lj * W, gi = gi0 + li, gj = gj0 + lj;
-    const bool in = gi >= 0 && gj >= 0 && gi <= n && gj <= n;
-    B[p] = in ? b[gj * st + gi] : 0.0;
+    if (PER) B[p] = b[pw2(gj, n) * st + pw2(gi, n)];
+    else {
+      const bool in = gi >= 0 && gj >= 0 && gi <= n && gj <= n;
+      B[p] = in ? b[gj * st + gi] : 0.0;
+    }
     X[p] = 0.0;
   }
   __syncthreads();
-  p1_tile_sweeps<W>(X, B, n, gi0, gj0, NSW, false);
+  p1_tile_sweeps<W, PER>(X, B, n, gi0, gj0, NSW, false);
   // store the tile's x, then overwrite B by the residual (r_p needs b_p and x only)
   {
     const int p = threadIdx.x;  // HDG_P1_TS^2 == HDG_P1_THREADS
     const int tj = p / HDG_P1_TS, ti = p - tj * HDG_P1_TS, gi = i0 + ti, gj = j0 + tj;
-    if (gi <= n && gj <= n) xpre[gj * st + gi] = X[(tj + H) * W + ti + H];
+    if (gi <= last && gj <= last) xpre[gj * st + gi] = X[(tj + H) * W + ti + H];
   }
   for (int p = threadIdx.x; p < W * W; p += HDG_P1_THREADS) {
     const int lj = p / W, li = p - lj * W, gi = gi0 + li, gj = gj0 + lj;
-    if (gi < 0 || gj < 0 || gi > n || gj > n) continue;
+    if (!PER && (gi < 0 || gj < 0 || gi > n || gj > n)) continue;
     double diag, off;
-    if (p1_stencil_tile<W>(X, n, gi, gj, li, lj, diag, off)) B[p] = B[p] - (diag * X[p] - off);
+    if (p1_stencil_tile<W, PER>(X, n, gi, gj, li, lj, diag, off)) B[p] = B[p] - (diag * X[p] - off);
   }
   __syncthreads();
   constexpr int HT = HDG_P1_TS / 2;
@@ -2966,22 +2978,27 @@ __global__ __launch_bounds__(HDG_P1_THREADS) void k_p1_down(int n, const double*
   if (threadIdx.x < HT * HT) {
     const int p = threadIdx.x;
     const int tJ = p / HT, tI = p - tJ * HT, i = i0 + 2 * tI, j = j0 + 2 * tJ;
-    if (i <= n && j <= n) {
+    if (i <= last && j <= last) {
       const int li = i - gi0, lj = j - gj0;
-      double acc = B[lj * W + li];
-      if (i > 0) acc += 0.5 * B[lj * W + li - 1];
-      if (i < n) acc += 0.5 * B[lj * W + li + 1];
-      if (j > 0) acc += 0.5 * B[(lj - 1) * W + li];
-      if (j < n) acc += 0.5 * B[(lj + 1) * W + li];
-      if (i > 0 && j < n) acc += 0.5 * B[(lj + 1) * W + li - 1];
-      if (i < n && j > 0) acc += 0.5 * B[(lj - 1) * W + li + 1];
-      bc[(j >> 1) * (nc + 1) + (i >> 1)] = acc;
+      if (PER) {  // (the order of k_p1p_restrict)
+        bc[(j >> 1) * nc + (i >> 1)] = B[lj * W + li] + 0.5 * (B[lj * W + li - 1] + B[lj * W + li + 1] + B[(lj - 1) * W + li] + B[(lj + 1) * W + li] +
+                                                                 B[(lj + 1) * W + li - 1] + B[(lj - 1) * W + li + 1]);
+      } else {
+        double acc = B[lj * W + li];
+        if (i > 0) acc += 0.5 * B[lj * W + li - 1];
+        if (i < n) acc += 0.5 * B[lj * W + li + 1];
+        if (j > 0) acc += 0.5 * B[(lj - 1) * W + li];
+        if (j < n) acc += 0.5 * B[(lj + 1) * W + li];
+        if (i > 0 && j < n) acc += 0.5 * B[(lj + 1) * W + li - 1];
+        if (i < n && j > 0) acc += 0.5 * B[(lj - 1) * W + li + 1];
+        bc[(j >> 1) * (nc + 1) + (i >> 1)] = acc;
+      }
     }
   }
 }
 // up leg: x = xpre + P xc, nsw sweeps with the colours reversed.  xpre (the down leg's result) and x are
 // DIFFERENT buffers: a workgroup reads the halo of its tile while its neighbours store theirs.
-template <int NSW>
+template <int NSW, bool PER = false>
 __global__ __launch_bounds__(HDG_P1_THREADS) void k_p1_up(int n, const double* __restrict__ xc, const double* __restrict__ b,
                                                           const double* __restrict__ xpre, double* __restrict__ x, int jt0 = 0, int extra = 0, int period = 2,
                                                           SideXP sj = SideXP{}) {
@@ -2989,26 +3006,29 @@ __global__ __launch_bounds__(HDG_P1_THREADS) void k_p1_up(int n, const double* _
   __shared__ double X[W * W];
   __shared__ double B[W * W];
   HDG_P1_SIDE_JOB
-  const int st = n + 1, nc = n >> 1, sc = nc + 1;
+  const int st = PER ? n : n + 1, last = PER ? n - 1 : n, nc = n >> 1, sc = PER ? nc : nc + 1;
   const int i0 = blockIdx.x * HDG_P1_TS, j0 = (by + jt0) * HDG_P1_TS, gi0 = i0 - H, gj0 = j0 - H;  // jt0: first tile row of this launch
   for (int p = threadIdx.x; p < W * W; p += HDG_P1_THREADS) {
-    const int lj = p / W, li = p - lj * W, i = gi0 + li, j = gj0 + lj;
-    if (i < 0 || j < 0 || i > n || j > n) { X[p] = 0.0; B[p] = 0.0; continue; }
+    const int lj = p / W, li = p - lj * W;
+    int i = gi0 + li, j = gj0 + lj;
+    if (PER) { i = pw2(i, n); j = pw2(j, n); }
+    else if (i < 0 || j < 0 || i > n || j > n) { X[p] = 0.0; B[p] = 0.0; continue; }
     const int I = i >> 1, J = j >> 1;
+    const int I1 = PER ? (I + 1 == nc ? 0 : I + 1) : I + 1, J1 = PER ? (J + 1 == nc ? 0 : J + 1) : J + 1;
     double v;
     if (!(i & 1) && !(j & 1)) v = xc[J * sc + I];
-    else if ((i & 1) && !(j & 1)) v = 0.5 * (xc[J * sc + I] + xc[J * sc + I + 1]);
-    else if (!(i & 1) && (j & 1)) v = 0.5 * (xc[J * sc + I] + xc[(J + 1) * sc + I]);
-    else v = 0.5 * (xc[J * sc + I + 1] + xc[(J + 1) * sc + I]);
+    else if ((i & 1) && !(j & 1)) v = 0.5 * (xc[J * sc + I] + xc[J * sc + I1]);
+    else if (!(i & 1) && (j & 1)) v = 0.5 * (xc[J * sc + I] + xc[J1 * sc + I]);
+    else v = 0.5 * (xc[J * sc + I1] + xc[J1 * sc + I]);
     X[p] = xpre[j * st + i] + v;
     B[p] = b[j * st + i];
   }
   __syncthreads();
-  p1_tile_sweeps<W>(X, B, n, gi0, gj0, NSW, true);
+  p1_tile_sweeps<W, PER>(X, B, n, gi0, gj0, NSW, true);
   {
     const int p = threadIdx.x;
     const int tj = p / HDG_P1_TS, ti = p - tj * HDG_P1_TS, gi = i0 + ti, gj = j0 + tj;
-    if (gi <= n && gj <= n) x[gj * st + gi] = X[(tj + H) * W + ti + H];
+    if (gi <= last && gj <= last) x[gj * st + gi] = X[(tj + H) * W + ti + H];
   }
 }
 

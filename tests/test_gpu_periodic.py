@@ -116,6 +116,30 @@ def test_periodic_steps_through_the_tiled_trace_preconditioner(hip_lib, k, nx):
     assert np.all((sums / np.maximum(cnt, 1))[1:] < 25)
 
 
+@pytest.mark.parametrize("k,nx", [(2, 64), (1, 128), (2, 80)])
+def test_periodic_fused_vcycle_legs_equal_the_per_level_kernels(hip_lib, tmp_path, k, nx):
+    """The vertex-grid V-cycle of the periodic square with the fused LDS-tile legs (k_p1_down / k_p1_up, PER = true: wrapped
+    loads, every vertex interior) for n > 32 and the tail n <= 32 as one dense product, carrying the p / x half of the CG update
+    as side jobs -- against the per-level kernels (HDG_MG_NO_FUSE, read once per process: two worker processes).  The legs form
+    every vertex value by the same expression in the same order, the dense tail is the same linear map to rounding: fields at
+    1e-9, same CG counts.  64: one leg level above the tail; 128: two; 80: tiles that wrap inside their halo (80 = 2.5 tiles)."""
+    import os
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    res = {}
+    for tag, env in (("fused", {}), ("levels", {"HDG_MG_NO_FUSE": "1"})):
+        out = str(tmp_path / f"{tag}.npz")
+        r = subprocess.run([sys.executable, os.path.join(here, "periodic_worker.py"), str(k), str(nx), "2", out], env=dict(os.environ, **env),
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+        assert r.returncode == 0, r.stdout.decode()[-2000:]
+        res[tag] = np.load(out)
+    for name in ("Q", "p", "lam"):
+        assert _rel(res["fused"][name], res["levels"][name]) < 1e-9, name
+    assert np.all(np.abs(res["fused"]["its"][1:] - res["levels"]["its"][1:]) <= 1.0), (res["fused"]["its"], res["levels"]["its"])
+
+
 @pytest.mark.parametrize("k,nx", [(1, 4), (2, 4), (3, 4), (2, 6)])
 def test_periodic_continuous_space_tracer_operator_vorticity(hip_lib, k, nx):
     """CG_{k+1} on the periodic square (nx x ny corners, indices wrap): projection (common.py:119-122), tracer transport
