@@ -230,4 +230,98 @@ __global__ __launch_bounds__(128) void k_tracer_adv(Geo g, DevTables T, const do
   store_cell<NP>(out, g.Nc, c, F);
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Jacobi-preconditioned CG on the continuous-space mass matrix for TWO right-hand sides at once (the two components of the
+// velocity projection, common.py:119-122), scalars on the device: per iteration two mass applications, one kernel for the two
+// (p, M p), one update kernel (x += alpha p, r -= alpha M p, and (r, r / d) of the new residual in the same pass), one
+// direction kernel (p = r / d + beta p), two one-workgroup kernels that finish the reductions and form alpha / beta -- 11
+// launches and NO host synchronisation for both components, where the one-vector loop of round 3 (Engine::cg_solve) took
+// 20 launches and 4 host round trips.  sc[8 d + ..]: 0 rz, 1 alpha, 2 beta, 3 rz0; sc[16]: both converged (host poll).
+// ------------------------------------------------------------------------------------------
+#define HDG_CGM_BLOCK 256
+__global__ void k_cgm_pap2(long n, const double* __restrict__ p0, const double* __restrict__ a0, const double* __restrict__ p1,
+                           const double* __restrict__ a1, double* __restrict__ part) {
+  double s0 = 0.0, s1 = 0.0;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    s0 = fma(p0[i], a0[i], s0);
+    s1 = fma(p1[i], a1[i], s1);
+  }
+  __shared__ double sm[HDG_CGM_BLOCK / 64][2];
+  const double w0 = wave_sum(s0), w1 = wave_sum(s1);
+  if ((threadIdx.x & 63) == 0) { sm[threadIdx.x >> 6][0] = w0; sm[threadIdx.x >> 6][1] = w1; }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    double t = 0.0;
+    for (int w = 0; w < HDG_CGM_BLOCK / 64; w++) t += sm[w][threadIdx.x];
+    part[(long)threadIdx.x * gridDim.x + blockIdx.x] = t;
+  }
+}
+// finishes a two-value reduction (part[q * nb + b]) and forms the scalars.  mode 0: the values are (p, M p): alpha = rz / pAp;
+// mode 1: the values are the new (r, z): beta = new / old, convergence flag; mode 2: first residual: rz = rz0 = value, beta = 0
+__global__ void k_cgm_scalars(int nb, int mode, double tol2, const double* __restrict__ part, double* __restrict__ sc, double* __restrict__ hflag) {
+  __shared__ double sm[HDG_CGM_BLOCK / 64][2];
+  double s0 = 0.0, s1 = 0.0;
+  for (int b = threadIdx.x; b < nb; b += blockDim.x) { s0 += part[b]; s1 += part[(long)nb + b]; }
+  const double w0 = wave_sum(s0), w1 = wave_sum(s1);
+  if ((threadIdx.x & 63) == 0) { sm[threadIdx.x >> 6][0] = w0; sm[threadIdx.x >> 6][1] = w1; }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  double v[2] = {0.0, 0.0};
+  for (int w = 0; w < HDG_CGM_BLOCK / 64; w++) { v[0] += sm[w][0]; v[1] += sm[w][1]; }
+  int conv = 0;
+  for (int d = 0; d < 2; d++) {
+    double* s = sc + 8 * d;
+    if (mode == 0) s[1] = (v[d] > 0.0 && s[0] > 0.0) ? s[0] / v[d] : 0.0;  // a converged (or zero) component stands still
+    else if (mode == 1) { s[2] = s[0] > 0.0 ? v[d] / s[0] : 0.0; s[0] = v[d]; }
+    else { s[0] = s[3] = v[d]; s[2] = 0.0; }
+    if (!(s[0] > tol2 * s[3])) conv++;
+  }
+  sc[16] = conv == 2 ? 1.0 : 0.0;
+  if (hflag) { hflag[0] = sc[16]; hflag[1] = sc[0]; hflag[2] = sc[8]; }
+}
+// x += alpha p ; r -= alpha M p ; partial sums of (r, r / d) of the new residual.  first != 0: only the sums (r = b, x = 0 before)
+__global__ void k_cgm_update2(long n, int first, const double* __restrict__ sc, const double* __restrict__ dg, const double* __restrict__ p0,
+                              const double* __restrict__ a0, double* __restrict__ x0, double* __restrict__ r0, const double* __restrict__ p1,
+                              const double* __restrict__ a1, double* __restrict__ x1, double* __restrict__ r1, double* __restrict__ part) {
+  const double al0 = first ? 0.0 : sc[1], al1 = first ? 0.0 : sc[9];
+  double s0 = 0.0, s1 = 0.0;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const double di = 1.0 / dg[i];
+    double ra = r0[i], rb = r1[i];
+    if (!first) {
+      x0[i] = fma(al0, p0[i], x0[i]);
+      x1[i] = fma(al1, p1[i], x1[i]);
+      ra = fma(-al0, a0[i], ra);
+      rb = fma(-al1, a1[i], rb);
+      r0[i] = ra;
+      r1[i] = rb;
+    }
+    s0 = fma(ra * di, ra, s0);
+    s1 = fma(rb * di, rb, s1);
+  }
+  __shared__ double sm[HDG_CGM_BLOCK / 64][2];
+  const double w0 = wave_sum(s0), w1 = wave_sum(s1);
+  if ((threadIdx.x & 63) == 0) { sm[threadIdx.x >> 6][0] = w0; sm[threadIdx.x >> 6][1] = w1; }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    double t = 0.0;
+    for (int w = 0; w < HDG_CGM_BLOCK / 64; w++) t += sm[w][threadIdx.x];
+    part[(long)threadIdx.x * gridDim.x + blockIdx.x] = t;
+  }
+}
+// p = r / d + beta p
+__global__ void k_cgm_dir2(long n, const double* __restrict__ sc, const double* __restrict__ dg, const double* __restrict__ r0, double* __restrict__ p0,
+                           const double* __restrict__ r1, double* __restrict__ p1) {
+  const double b0 = sc[2], b1 = sc[10];
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const double di = 1.0 / dg[i];
+    p0[i] = (b0 == 0.0) ? r0[i] * di : fma(b0, p0[i], r0[i] * di);  // (beta = 0: the buffer may hold anything)
+    p1[i] = (b1 == 0.0) ? r1[i] * di : fma(b1, p1[i], r1[i] * di);
+  }
+}
+
 }  // namespace hdg

@@ -574,6 +574,8 @@ struct Engine {
     if (ev_in) { (void)hipEventDestroy(ev_in); ev_in = nullptr; }
     if (ev_halo) { (void)hipEventDestroy(ev_halo); ev_halo = nullptr; }
     if (cstream) { (void)hipStreamDestroy(cstream); cstream = nullptr; }
+    if (h_cgm) { (void)hipHostFree(h_cgm); h_cgm = nullptr; }
+    for (int q = 0; q < 2; q++) if (cgm_ev[q]) { (void)hipEventDestroy(cgm_ev[q]); cgm_ev[q] = nullptr; }
     if (ev_x0) { (void)hipEventDestroy(ev_x0); ev_x0 = nullptr; }
     if (ev_x1) { (void)hipEventDestroy(ev_x1); ev_x1 = nullptr; }
     if (xstream) { (void)hipStreamDestroy(xstream); xstream = nullptr; }
@@ -3948,6 +3950,46 @@ struct Engine {
     }
     throw NotConverged{"continuous-space mass solve did not converge"};
   }
+  // The same solve for TWO right-hand sides at once (structured meshes: the two components of cg_project), scalars on the device,
+  // no host synchronisation inside an iteration (hdg_cg.hpp: k_cgm_*): r0 / r1 hold the right-hand sides on entry and the
+  // residuals afterwards, the solutions come out in x0 / x1.  Convergence as in cg_solve (1e-13 on the preconditioned residual
+  // of EACH component), read by the host one iteration late.  HDG_CG_MASS_ONE_BY_ONE: the one-vector loop.
+  double *cg_b2 = nullptr, *cg_x2 = nullptr, *cg_pp2 = nullptr, *cg_Ap3 = nullptr, *d_cgm = nullptr, *h_cgm = nullptr;
+  hipEvent_t cgm_ev[2] = {nullptr, nullptr};
+  void cg_solve2(double* r0, double* r1, double* x0, double* x1) {
+    const long n = cgt.ncg;
+    if (!d_cgm) {
+      d_cgm = dalloc(24);
+      HIPCHECK(hipHostMalloc((void**)&h_cgm, sizeof(double) * 8));
+      for (int q = 0; q < 2; q++) HIPCHECK(hipEventCreateWithFlags(&cgm_ev[q], hipEventDisableTiming));
+    }
+    const int nb = std::min(std::min(dot_blocks, vec_blocks(n)), 1024);
+    const double tol2 = 1e-26;
+    zero(x0, n); zero(x1, n);
+    k_cgm_update2<<<nb, HDG_CGM_BLOCK, 0, stream>>>(n, 1, d_cgm, cg_dinv, cg_pp, cg_Ap2, x0, r0, cg_pp2, cg_Ap3, x1, r1, d_part);
+    k_cgm_scalars<<<1, HDG_CGM_BLOCK, 0, stream>>>(nb, 2, tol2, d_part, d_cgm, h_cgm);
+    HIPCHECK(hipStreamSynchronize(stream));
+    cg_its_last = 0;
+    if (h_cgm[0] == 1.0) return;  // both right-hand sides vanish
+    k_cgm_dir2<<<vec_blocks(n), 256, 0, stream>>>(n, d_cgm, cg_dinv, r0, cg_pp, r1, cg_pp2);
+    for (int it = 1; it <= 500; it++) {
+      cg_mass(cg_pp, cg_Ap2);
+      cg_mass(cg_pp2, cg_Ap3);
+      k_cgm_pap2<<<nb, HDG_CGM_BLOCK, 0, stream>>>(n, cg_pp, cg_Ap2, cg_pp2, cg_Ap3, d_part);
+      k_cgm_scalars<<<1, HDG_CGM_BLOCK, 0, stream>>>(nb, 0, tol2, d_part, d_cgm, nullptr);
+      k_cgm_update2<<<nb, HDG_CGM_BLOCK, 0, stream>>>(n, 0, d_cgm, cg_dinv, cg_pp, cg_Ap2, x0, r0, cg_pp2, cg_Ap3, x1, r1, d_part);
+      k_cgm_scalars<<<1, HDG_CGM_BLOCK, 0, stream>>>(nb, 1, tol2, d_part, d_cgm, h_cgm + 4 * (it & 1));
+      HIPCHECK(hipEventRecord(cgm_ev[it & 1], stream));
+      k_cgm_dir2<<<vec_blocks(n), 256, 0, stream>>>(n, d_cgm, cg_dinv, r0, cg_pp, r1, cg_pp2);
+      if (it >= 2) {  // the flag of the previous iteration has long arrived; x has taken one more (harmless) step by now
+        HIPCHECK(hipEventSynchronize(cgm_ev[(it - 1) & 1]));
+        const double* f = h_cgm + 4 * ((it - 1) & 1);
+        if (!(f[1] == f[1]) || !(f[2] == f[2])) throw NotConverged{"continuous-space mass solve: NaN residual"};
+        if (f[0] == 1.0) { cg_its_last = it - 1; return; }
+      }
+    }
+    throw NotConverged{"continuous-space mass solve did not converge"};
+  }
   // L2 projection of a broken velocity onto [CG_{k+1}]^2 (common.py:119-122); result as a broken modal vector
   void cg_project(const double* vel_in, double* vel_out) {
     cg_setup();
@@ -3957,6 +3999,20 @@ struct Engine {
         cg_solve();
         csr(gcgd.Ep[d], cg_x, 1.0, d == 0 ? 0.0 : 1.0, vel_out);  // component 0 clears the rows of component 1, which then adds
       }
+      return;
+    }
+    static const bool one_by_one = std::getenv("HDG_CG_MASS_ONE_BY_ONE") != nullptr;
+    if (!one_by_one) {  // both components in one solve
+      if (!cg_b2) for (double** v : {&cg_b2, &cg_x2, &cg_pp2, &cg_Ap3}) *v = dalloc(cgt.ncg);
+      for (int d = 0; d < 2; d++) {
+        HDG_DISPATCH(k_cg_cell<KK, 1><<<cell_grid(), bs(), 0, stream>>>(g, cgt, dt, cg_Mloc, dt.Vuinv, nullptr, nullptr, nullptr, nullptr,
+                                                                         nullptr, nullptr, const_cast<double*>(vel_in), d, cg_y));
+        HDG_DISPATCH(k_cg_gather<KK><<<corner_grid_all(), bs(), 0, stream>>>(g_all, cgt, cg_y, d == 0 ? cg_b : cg_b2));
+      }
+      cg_solve2(cg_b, cg_b2, cg_x, cg_x2);
+      for (int d = 0; d < 2; d++)
+        HDG_DISPATCH(k_cg_cell<KK, 2><<<cell_grid(), bs(), 0, stream>>>(g, cgt, dt, cg_Mloc, dt.Vuinv, nullptr, nullptr, nullptr, nullptr,
+                                                                         nullptr, d == 0 ? cg_x : cg_x2, vel_out, d, nullptr));
       return;
     }
     for (int d = 0; d < 2; d++) {
